@@ -1,0 +1,513 @@
+// rt_core.hpp — per-ray / per-hit device functions of the MI355X render path.
+//
+// Everything here is written once and compiled twice: by hipcc into the gfx950 kernels
+// (rt_kernels.hip) and by g++ into a test-only host emulation (tests/emul/) that lets the CPU
+// test-suite exercise the exact device arithmetic.  The product never runs the host build.
+//
+// Arithmetic contract (what makes the GPU agree with the reference bit for bit in the
+// deterministic modes): fp32, no FMA contraction (-ffp-contract=off; x86-64 g++ -O2 emits none
+// for the reference), IEEE divide and sqrt, glm's operation order (dot = (x+y)+z, normalize =
+// v*(1/sqrt(dot)), reflect = I - N*dot(N,I)*2; reference include/glm/detail/func_geometric.inl).
+// Explicit fmaf() appears only in the conservative BVH culling test, which never decides a
+// result on its own (every accepted hit comes from the exact tests below).
+#pragma once
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "rt_amd.h"
+#include "rt_rng.h"
+
+#if defined(__HIPCC__)
+#define RT_FN __host__ __device__ inline
+#else
+#define RT_FN inline
+#endif
+
+namespace rt {
+
+struct alignas(16) q4 { float x, y, z, w; };
+struct f3 { float x, y, z; };
+
+RT_FN uint32_t f2u(float f) { union { float f; uint32_t u; } c; c.f = f; return c.u; }
+RT_FN float u2f(uint32_t u) { union { float f; uint32_t u; } c; c.u = u; return c.f; }
+
+RT_FN f3 F3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_FN f3 xyz(const q4& q) { return F3(q.x, q.y, q.z); }
+RT_FN f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_FN f3 operator-(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_FN f3 operator*(f3 a, f3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_FN f3 operator*(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s); }
+RT_FN f3 operator/(f3 a, float s) { return F3(a.x / s, a.y / s, a.z / s); }
+RT_FN f3 operator-(f3 a) { return F3(-a.x, -a.y, -a.z); }
+RT_FN float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_FN f3 cross(f3 x, f3 y) { return F3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
+RT_FN f3 normalize(f3 v) { return v * (1.0f / sqrtf(dot(v, v))); }
+RT_FN float length(f3 v) { return sqrtf(dot(v, v)); }
+RT_FN f3 reflect(f3 I, f3 N) { return I - N * dot(N, I) * 2.0f; }
+RT_FN float clampf(float x, float lo, float hi) { float m = (x < lo) ? lo : x; return (hi < m) ? hi : m; }
+RT_FN f3 clamp01(f3 L) { return F3(clampf(L.x, 0.0f, 1.0f), clampf(L.y, 0.0f, 1.0f), clampf(L.z, 0.0f, 1.0f)); }
+
+// ---- flattened scene (built by rt_scene.cpp, resident in HBM) -------------------------------
+enum : uint32_t { G_GROUP = 0, G_GATED = 1, G_PLANE = 2, G_SPHERE = 3, G_TRI = 4, G_MESH = 5 };
+
+// Shape-level structure of the reference, in depth-first preorder with skip pointers (no stack):
+// world->scene entries, BVHAccel internal nodes, MultiMesh and Mesh gates.  A gated node is
+// entered only if the reference's own box test passes (BoundingVolumeBox::intersects).
+struct alignas(16) GateNode {
+    float mn[3]; uint32_t kind;
+    float mx[3]; uint32_t skip;  // next node when this subtree is not entered
+    uint32_t a;                  // PLANE/SPHERE: index; TRI: triangle slot; MESH: root of its triangle BVH
+    uint32_t rank;               // reference visiting order of the (first) primitive below
+    uint32_t prim;               // MESH: global triangle index of its triangle 0
+    uint32_t item;               // world->scene entry this node belongs to
+};
+
+// hit.prim encoding
+enum : uint32_t { H_PLANE = 0u << 30, H_SPHERE = 1u << 30, H_TRI = 2u << 30, H_MISS = 0xFFFFFFFFu, H_MASK = 0x3FFFFFFFu };
+
+struct DMaterial { int32_t kind; float colour[3]; float kd, ka, ks; int32_t spec_exp; float ior; int32_t texture; float pad0, pad1; };
+struct DLight { int32_t kind; float v[3]; float colour[3]; float radiance; };
+struct DTexture { uint32_t offset; int32_t width, height; int32_t set; };
+
+struct DScene {
+    const GateNode* gates; uint32_t num_gates;
+    const q4* planes;    // 2 / plane : {point, bits(material)} {normal, 0}
+    const q4* spheres;   // 2 / sphere: {centre, radius} {radius^2, bits(material), 0, 0}
+    const q4* tris;      // 3 / slot  : {v0, bits(global tri)} {e1=v1-v0, bits(material)} {e2=v2-v0, bits(rank offset)}
+    const q4* tri_attr;  // 2 / global triangle: {uv0, uv1} {uv2, 0, 0}
+    const q4* nodes;     // 4 / BVH2 node (64 B): both child boxes + child refs
+    const DMaterial* materials;
+    const DLight* lights; uint32_t num_lights;
+    const DTexture* textures; const uint8_t* texels; uint32_t num_textures;
+    const uint8_t* item_opaque; uint32_t num_items;  // 1: no transparent material below this scene entry
+    rt_ambient ambient;
+    uint32_t prim_base_sphere, prim_base_tri;
+    float cull_pad;      // conservative padding of the BVH culling test, relative (see bvh_traverse)
+    float extent;        // largest |coordinate| of the scene
+};
+
+// BVH child reference: bit31 = leaf, bits 28..30 = triangle count-1, bits 0..27 = first slot
+enum : uint32_t { REF_LEAF = 0x80000000u, REF_NONE = 0x7FFFFFFFu };
+
+struct Counters { uint32_t nodes, tris, gates; };
+
+struct Stack { uint32_t* p; uint32_t stride; };  // entry i lives at p[i*stride] (LDS: stride = threads per block)
+#define RT_STACK_DEPTH 32
+
+struct Hit { float t; uint32_t prim; float u, v; uint32_t rank; };
+
+// ---- exact primitive tests (each cites the reference code it reproduces) -----------------------
+
+// atlas::core::geq  (include/atlas/core/Float.hpp:17-21,49-52)
+RT_FN bool geq(float a, float b)
+{
+    if (a > b) return true;
+    float scale = (fabsf(a) + fabsf(b)) / 2.0f;
+    return fabsf(a - b) <= FLT_EPSILON * scale;
+}
+
+// Plane::intersectRay (main.cpp:943-957) with tMin = FLT_MAX
+RT_FN bool plane_t(f3 point, f3 normal, f3 o, f3 d, float& t)
+{
+    float denom = dot(normal, d);
+    if (fabsf(denom) < 0.00001f) return false;
+    float tt = dot(point - o, normal) / denom;
+    if (tt >= 0 && tt < FLT_MAX) { t = tt; return true; }
+    return false;
+}
+
+// One face of BoundingVolumeBox::intersects (main.cpp:245-296).  For an axis-aligned unit normal
+// the reference's dot products reduce exactly to (c - o[a]) / d[a].
+RT_FN bool box_face(int axis, float c, const float* mn, const float* mx, f3 o, f3 d)
+{
+    float oa = axis == 0 ? o.x : (axis == 1 ? o.y : o.z);
+    // denom = dot(unit axis, d) and dot(p - o, unit axis): the zero products vanish for finite rays
+    float denom = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
+    if (fabsf(denom) < 0.00001f) return false;
+    float t = (c - oa) / denom;
+    if (!(t >= 0 && t < FLT_MAX)) return false;
+    f3 h = o + d * t;
+    if (axis == 0) return h.y > mn[1] && h.y < mx[1] && h.z > mn[2] && h.z < mx[2];
+    if (axis == 1) return h.x > mn[0] && h.x < mx[0] && h.z > mn[2] && h.z < mx[2];
+    return h.x > mn[0] && h.x < mx[0] && h.y > mn[1] && h.y < mx[1];
+}
+
+RT_FN bool box_intersects(const float* mn, const float* mx, f3 o, f3 d)
+{
+    return box_face(0, mn[0], mn, mx, o, d) || box_face(0, mx[0], mn, mx, o, d) ||
+           box_face(1, mn[1], mn, mx, o, d) || box_face(1, mx[1], mn, mx, o, d) ||
+           box_face(2, mn[2], mn, mx, o, d) || box_face(2, mx[2], mn, mx, o, d);
+}
+
+// Sphere::intersectRay (main.cpp:600-633): far root not divided by 2a
+RT_FN bool sphere_t(f3 centre, float radius_sqr, f3 o, f3 d, float& t)
+{
+    f3 tmp = o - centre;
+    float a = dot(d, d);
+    float b = 2.0f * dot(d, tmp);
+    float c = dot(tmp, tmp) - radius_sqr;
+    float disc = (b * b) - (4.0f * a * c);
+    if (geq(disc, 0.0f)) {
+        const float kEpsilon = 0.01f;
+        float e = sqrtf(disc);
+        float denom = 2.0f * a;
+        float tt = (-b - e) / denom;
+        if (geq(tt, kEpsilon)) { t = tt; return true; }
+        tt = (-b + e);
+        if (geq(tt, kEpsilon)) { t = tt; return true; }
+    }
+    return false;
+}
+
+// Triangle::intersectRay, 3-argument overload (main.cpp:713-739): single-sided, any sign of t
+RT_FN bool tri_t(f3 v0, f3 v0v1, f3 v0v2, f3 o, f3 d, float& t, float& u, float& v)
+{
+    f3 pvec = cross(d, v0v2);
+    float det = dot(v0v1, pvec);
+    if (det < 0.000001f) return false;
+    float invDet = 1.0f / det;
+    f3 tvec = o - v0;
+    float uu = dot(tvec, pvec) * invDet;
+    if (uu < 0 || uu > 1) return false;
+    f3 qvec = cross(tvec, v0v1);
+    float vv = dot(d, qvec) * invDet;
+    if (vv < 0 || uu + vv > 1) return false;
+    t = dot(v0v2, qvec) * invDet;
+    u = uu; v = vv;
+    return true;
+}
+
+// `if (intersect && t < sr.t)` of every Shape::hit, plus the reference's first-wins order on ties
+RT_FN bool closer(float t, uint32_t rank, const Hit& h) { return t < h.t || (t == h.t && h.prim != H_MISS && rank < h.rank); }
+
+// ---- triangle BVH of one Mesh ------------------------------------------------------------------
+// The reference scans every triangle of a Mesh whose box gate passed and keeps the smallest t of
+// ANY sign, i.e. the query is a line, not a ray.  So the BVH is traversed over the
+// interval (-inf, best.t): children are culled with a slab test padded by
+// pad = cull_pad * (|o|_inf + extent) so that float rounding in the reference's Moller-Trumbore
+// arithmetic can never accept a triangle whose box was culled.  Culling never decides a hit.
+struct RayCull { float ix, iy, iz, lx, ly, lz, hx, hy, hz; };
+
+RT_FN RayCull make_cull(const DScene& S, f3 o, f3 d)
+{
+    RayCull c;
+    float pad = S.cull_pad * (fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) + S.extent);
+    float dx = fabsf(d.x) > 1e-20f ? d.x : (d.x < 0 ? -1e-20f : 1e-20f);
+    float dy = fabsf(d.y) > 1e-20f ? d.y : (d.y < 0 ? -1e-20f : 1e-20f);
+    float dz = fabsf(d.z) > 1e-20f ? d.z : (d.z < 0 ? -1e-20f : 1e-20f);
+    c.ix = 1.0f / dx; c.iy = 1.0f / dy; c.iz = 1.0f / dz;
+    c.lx = -(o.x + pad) * c.ix; c.hx = -(o.x - pad) * c.ix;
+    c.ly = -(o.y + pad) * c.iy; c.hy = -(o.y - pad) * c.iy;
+    c.lz = -(o.z + pad) * c.iz; c.hz = -(o.z - pad) * c.iz;
+    return c;
+}
+
+RT_FN bool cull_box(const RayCull& c, float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                    float tbest, float& tnear)
+{
+    float ax = fmaf(mnx, c.ix, c.lx), bx = fmaf(mxx, c.ix, c.hx);
+    float ay = fmaf(mny, c.iy, c.ly), by = fmaf(mxy, c.iy, c.hy);
+    float az = fmaf(mnz, c.iz, c.lz), bz = fmaf(mxz, c.iz, c.hz);
+    float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    float f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    tnear = n;
+    // widen by a relative slack for the rounding of the slab arithmetic itself
+    float slack = 4e-6f * fmaxf(fabsf(n), fabsf(f));
+    return (n - slack <= f + slack) && (n - slack <= tbest);
+}
+
+template <bool STATS, bool ANYHIT>
+RT_FN bool bvh_traverse(const DScene& S, const GateNode& g, f3 o, f3 d, const RayCull& rc, Hit& best,
+                        Stack st, Counters& cnt)
+{
+    uint32_t sp = 0;
+    uint32_t cur = g.a;
+    bool found = false;
+    for (;;) {
+        const q4* n = S.nodes + (size_t)cur * 4;
+        q4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+        if (STATS) cnt.nodes++;
+        uint32_t refs[2] = {f2u(n3.x), f2u(n3.y)};
+        float tn[2];
+        bool hit[2];
+        hit[0] = refs[0] != REF_NONE && cull_box(rc, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, best.t, tn[0]);
+        hit[1] = refs[1] != REF_NONE && cull_box(rc, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, best.t, tn[1]);
+        uint32_t next[2] = {REF_NONE, REF_NONE};
+        for (int c = 0; c < 2; ++c) {
+            if (!hit[c]) continue;
+            if (refs[c] & REF_LEAF) {
+                uint32_t first = refs[c] & 0x0FFFFFFFu, count = ((refs[c] >> 28) & 7u) + 1u;
+                for (uint32_t i = 0; i < count; ++i) {
+                    const q4* T = S.tris + (size_t)(first + i) * 3;
+                    q4 a = T[0], b = T[1], e = T[2];
+                    if (STATS) cnt.tris++;
+                    float t, u, v;
+                    if (tri_t(xyz(a), xyz(b), xyz(e), o, d, t, u, v)) {
+                        uint32_t rank = g.rank + f2u(e.w);
+                        if (closer(t, rank, best)) {
+                            best.t = t; best.prim = H_TRI | (first + i); best.u = u; best.v = v; best.rank = rank;
+                            found = true;
+                            if (ANYHIT) return true;
+                        }
+                    }
+                }
+            } else {
+                next[c] = refs[c];
+            }
+        }
+        if (next[0] != REF_NONE && next[1] != REF_NONE) {
+            bool swap = tn[1] < tn[0];
+            uint32_t nearc = swap ? next[1] : next[0], farc = swap ? next[0] : next[1];
+            if (sp < RT_STACK_DEPTH) st.p[(sp++) * st.stride] = farc;  // depth is bounded by the builder
+            cur = nearc;
+        } else if (next[0] != REF_NONE) {
+            cur = next[0];
+        } else if (next[1] != REF_NONE) {
+            cur = next[1];
+        } else {
+            if (sp == 0) break;
+            cur = st.p[(--sp) * st.stride];
+        }
+    }
+    return found;
+}
+
+// ---- one closest-hit query over world->scene ("one ray") ----------------------------------------
+// MODE 0: closest hit (`for obj in scene: hit |= obj->hit(ray, rec)`, main.cpp:1645-1648, 1390-1393,
+//         1457-1460, 1548-1551) with rec.t starting at tmax.
+// MODE 1: Material::shadowed (main.cpp:40-76): closest hit per world->scene entry with
+//         rec.t = tmax; returns 1, 0 or 0.8 in `shadow`.
+template <int MODE, bool STATS>
+RT_FN void trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& shadow, Stack st, Counters& cnt)
+{
+    best.t = tmax; best.prim = H_MISS; best.u = 0; best.v = 0; best.rank = 0;
+    RayCull rc = make_cull(S, o, d);
+    bool shadowed = false, transparentOnly = true;
+    uint32_t cur_item = 0;
+    uint32_t i = 0;
+    const uint32_t n = S.num_gates;
+    while (i < n) {
+        const GateNode g = S.gates[i];
+        if (MODE == 1 && g.item != cur_item) {
+            if (best.prim != H_MISS) {
+                shadowed = true;
+                uint32_t mat;
+                uint32_t k = best.prim & H_MASK;
+                if ((best.prim & ~H_MASK) == H_PLANE) mat = f2u(S.planes[k * 2].w);
+                else if ((best.prim & ~H_MASK) == H_SPHERE) mat = f2u(S.spheres[k * 2 + 1].y);
+                else mat = f2u(S.tris[(size_t)k * 3 + 1].w);
+                transparentOnly = transparentOnly && (S.materials[mat].kind == RT_MAT_REFRACTION);
+                if (!transparentOnly) break;
+            }
+            best.t = tmax; best.prim = H_MISS;
+            cur_item = g.item;
+        }
+        switch (g.kind) {
+        case G_GROUP:
+            i++;
+            break;
+        case G_GATED:
+            if (STATS) cnt.gates++;
+            i = box_intersects(g.mn, g.mx, o, d) ? i + 1 : g.skip;
+            break;
+        case G_PLANE: {
+            q4 p0 = S.planes[g.a * 2], p1 = S.planes[g.a * 2 + 1];
+            float t;
+            if (plane_t(xyz(p0), xyz(p1), o, d, t) && closer(t, g.rank, best)) {
+                best.t = t; best.prim = H_PLANE | g.a; best.rank = g.rank;
+            }
+            i++;
+            break;
+        }
+        case G_SPHERE: {
+            q4 s0 = S.spheres[g.a * 2], s1 = S.spheres[g.a * 2 + 1];
+            float t;
+            if (sphere_t(xyz(s0), s1.x, o, d, t) && closer(t, g.rank, best)) {
+                best.t = t; best.prim = H_SPHERE | g.a; best.rank = g.rank;
+            }
+            i++;
+            break;
+        }
+        case G_TRI: {
+            const q4* T = S.tris + (size_t)g.a * 3;
+            q4 a = T[0], b = T[1], e = T[2];
+            if (STATS) cnt.tris++;
+            float t, u, v;
+            if (tri_t(xyz(a), xyz(b), xyz(e), o, d, t, u, v) && closer(t, g.rank, best)) {
+                best.t = t; best.prim = H_TRI | g.a; best.u = u; best.v = v; best.rank = g.rank;
+            }
+            i++;
+            break;
+        }
+        default: { // G_MESH
+            if (STATS) cnt.gates++;
+            if (box_intersects(g.mn, g.mx, o, d)) {
+                if (MODE == 1 && S.item_opaque[g.item]) {
+                    if (bvh_traverse<STATS, true>(S, g, o, d, rc, best, st, cnt)) { shadowed = true; transparentOnly = false; i = n; break; }
+                } else {
+                    bvh_traverse<STATS, false>(S, g, o, d, rc, best, st, cnt);
+                }
+            }
+            i++;
+            break;
+        }
+        }
+    }
+    if (MODE == 1) {
+        if (i >= n && best.prim != H_MISS && !(shadowed && !transparentOnly)) {
+            // finalise the last world->scene entry
+            shadowed = true;
+            uint32_t mat;
+            uint32_t k = best.prim & H_MASK;
+            if ((best.prim & ~H_MASK) == H_PLANE) mat = f2u(S.planes[k * 2].w);
+            else if ((best.prim & ~H_MASK) == H_SPHERE) mat = f2u(S.spheres[k * 2 + 1].y);
+            else mat = f2u(S.tris[(size_t)k * 3 + 1].w);
+            transparentOnly = transparentOnly && (S.materials[mat].kind == RT_MAT_REFRACTION);
+        }
+        shadow = shadowed ? (transparentOnly ? 0.8f : 0.0f) : 1.0f;
+    }
+}
+
+// ---- camera + pixel samples -----------------------------------------------------------------------
+struct DCamera { f3 eye, U, V, W; float dist; };
+
+// Camera::Camera (main.cpp:1407-1413)
+RT_FN DCamera make_camera(const rt_camera& c)
+{
+    DCamera r;
+    r.eye = F3(c.eye[0], c.eye[1], c.eye[2]);
+    r.dist = c.frustum_dist;
+    r.W = normalize(r.eye - F3(c.look_at[0], c.look_at[1], c.look_at[2]));
+    r.V = normalize(cross(r.W, F3(c.up[0], c.up[1], c.up[2])));
+    r.U = normalize(cross(r.W, r.V));
+    return r;
+}
+
+// Camera::calculateRay (main.cpp:1420-1424)
+RT_FN f3 camera_dir(const DCamera& c, float x, float y) { return normalize((c.V * x + c.U * y) - c.W * c.dist); }
+
+// Sample point j of a pixel: the formulas of Regular/Jitter::generateSamples (main.cpp:986-987,
+// 1010-1011) fed by the counter hash instead of rand(); strata are walked in order (the reference
+// walks them in a shuffled order, which only permutes the terms of the pixel sum).
+RT_FN void sample_point(int sampler, int num_samples, uint32_t seed, uint32_t pixel, int j, float& sx, float& sy)
+{
+    int n = (int)sqrtf((float)num_samples);
+    if (n < 1) n = 1;
+    int jj = j % (n * n), pp = jj / n, q = jj % n;
+    if (sampler == RT_SAMPLER_REGULAR) { sx = (q + 0.5f) / n; sy = (pp + 0.5f) / n; return; }
+    int r0 = (int)rt_rand31(seed, pixel, (uint32_t)j, 0), r1 = (int)rt_rand31(seed, pixel, (uint32_t)j, 1);
+    if (sampler == RT_SAMPLER_RANDOM) {
+        sx = (float)(r0 >> 7) * (1.0f / 16777216.0f);
+        sy = (float)(r1 >> 7) * (1.0f / 16777216.0f);
+        return;
+    }
+    float gridSize = 1.0f / n;
+    sx = q * gridSize + ((float)r0 / (float)RT_RAND_MAX * gridSize);
+    sy = pp * gridSize + ((float)r1 / (float)RT_RAND_MAX * gridSize);
+}
+
+// ---- surface attributes of a hit ------------------------------------------------------------------
+struct Surface { f3 normal; int32_t material; float u, v; uint32_t prim_id; };
+
+RT_FN Surface surface_of(const DScene& S, const Hit& h, f3 o, f3 d)
+{
+    Surface s; s.u = 0; s.v = 0;
+    uint32_t k = h.prim & H_MASK, type = h.prim & ~H_MASK;
+    if (type == H_PLANE) { // Plane::hit (main.cpp:930-938)
+        q4 p0 = S.planes[k * 2], p1 = S.planes[k * 2 + 1];
+        s.normal = xyz(p1); s.material = (int32_t)f2u(p0.w); s.prim_id = k;
+    } else if (type == H_SPHERE) { // Sphere::hit (main.cpp:586-594): normal = (tmp + t*d)/r
+        q4 s0 = S.spheres[k * 2], s1 = S.spheres[k * 2 + 1];
+        s.normal = ((o - xyz(s0)) + d * h.t) / s0.w;
+        s.material = (int32_t)f2u(s1.y); s.prim_id = S.prim_base_sphere + k;
+    } else { // Triangle::hit (main.cpp:648-660)
+        const q4* T = S.tris + (size_t)k * 3;
+        q4 a = T[0], b = T[1], e = T[2];
+        uint32_t gid = f2u(a.w);
+        s.normal = normalize(cross(xyz(b), xyz(e)));
+        s.material = (int32_t)f2u(b.w);
+        q4 t0 = S.tri_attr[(size_t)gid * 2], t1 = S.tri_attr[(size_t)gid * 2 + 1];
+        float bz = 1.0f - h.u - h.v;
+        s.u = (t0.z * h.u + t1.x * h.v) + t0.x * bz;
+        s.v = (t0.w * h.u + t1.y * h.v) + t0.y * bz;
+        s.prim_id = S.prim_base_tri + gid;
+    }
+    return s;
+}
+
+// ---- lights -----------------------------------------------------------------------------------------
+RT_FN f3 light_pos(const DLight& l) { return F3(l.v[0], l.v[1], l.v[2]); }
+// getDirection / getSourcePoint (main.cpp:1320-1345); P = sr.ray(sr.t)
+RT_FN f3 light_direction(const DLight& l, f3 P) { return l.kind == RT_LIGHT_POINT ? light_pos(l) - P : light_pos(l); }
+RT_FN f3 light_source(const DLight& l, f3 P) { return l.kind == RT_LIGHT_POINT ? light_pos(l) : P + light_pos(l) * 1000000.0f; }
+RT_FN f3 light_L(const DLight& l) { return F3(l.colour[0], l.colour[1], l.colour[2]) * l.radiance; } // Light::L (main.cpp:551-554)
+
+// SpecularReflection::fn (main.cpp:1090-1105).  The reference evaluates ks*pow(vDotr, exp) in
+// double (std::pow(double,double)); exp is an int, so the power is formed by repeated squaring
+// in double and narrowed once.
+RT_FN float specular_fn(float ks, int exp, f3 normal, f3 wo, f3 wi)
+{
+    f3 r = reflect(wi, normal);
+    float vDotr = dot(r, -wo);
+    if (!(vDotr > 0.0f)) return 0.0f;
+    double base = (double)vDotr, acc = 1.0;
+    unsigned e = exp < 0 ? (unsigned)(-exp) : (unsigned)exp;
+    while (e) { if (e & 1u) acc *= base; base *= base; e >>= 1; }
+    if (exp < 0) acc = 1.0 / acc;
+    return (float)((double)ks * acc);
+}
+
+// ImageTexture::getColour (main.cpp:173-188); out-of-image reads are clamped to the image
+RT_FN f3 texture_colour(const DScene& S, int tex, float u, float v)
+{
+    if (tex < 0 || (uint32_t)tex >= S.num_textures) return F3(0, 0, 0);
+    DTexture T = S.textures[tex];
+    if (!T.set) return F3(0, 0, 0);
+    int x = (int)floorf(u * (float)T.width);
+    int y = (int)floorf(v * (float)T.height);
+    long long texel = (long long)x + (long long)T.height * y;
+    long long last = (long long)T.width * T.height - 1;
+    if (texel < 0) texel = 0;
+    if (texel > last) texel = last;
+    const uint8_t* px = S.texels + T.offset + texel * 4;
+    return F3((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+}
+
+// ---- ambient occlusion ray (Ambient::L, main.cpp:1361-1393; sampleHemisphere :4-19;
+//      rotationMatToSpace :21-34 and the mat4*vec4 product) ---------------------------------------
+RT_FN void ao_ray(const rt_ambient& A, f3 P, f3 N, uint32_t seed, uint32_t pixel, uint32_t sample,
+                  uint32_t ao_call, uint32_t k, f3& o, f3& dir)
+{
+    unsigned n = (unsigned)A.occlusion_samples;
+    uint32_t x = k / n, y = k % n;
+    uint32_t ctr = 2u + ao_call * 2u * n * n + k * 2u;
+    float grid = 1.0f / (float)n;
+    int r0 = (int)rt_rand31(seed, pixel, sample, ctr), r1 = (int)rt_rand31(seed, pixel, sample, ctr + 1);
+    float sampleX = (float)x * grid + (float)(((double)r0 / (double)RT_RAND_MAX) * (double)grid);
+    float sampleY = (float)y * grid + (float)(((double)r1 / (double)RT_RAND_MAX) * (double)grid);
+    float r = sqrtf(1.0f - sampleX * sampleX);
+    float phi = 2 * 3.14159265358979323846264338327950288f * sampleY;
+    // glibc's cosf/sinf are (almost always) correctly rounded; get the same bits from fp64
+    f3 h = F3((float)cos((double)phi) * r, sampleX, (float)sin((double)phi) * r);
+    f3 w = normalize(N);
+    f3 u = normalize(cross(w, F3(0.053f, 1.0f, 0.0332f)));
+    f3 v = cross(w, u);
+    f3 rr = (u * h.x + w * h.y) + (v * h.z + F3(0.0f, 0.0f, 0.0f));
+    dir = normalize(rr);
+    o = P + N * 0.01f;
+}
+
+// Transparency::refraction (main.cpp:1566-1592)
+RT_FN f3 refraction_dir(f3 d, f3 normal, float sr_ior, float& enter_ior)
+{
+    float cosi = clampf(dot(d, normal), -1.0f, 1.0f);
+    f3 n = normal;
+    if (cosi < 0) cosi = -cosi; else n = -normal;
+    float eta = sr_ior / enter_ior;
+    float k = 1 - eta * eta * (1 - cosi * cosi);
+    if (k < 0) { enter_ior = sr_ior; return reflect(d, n); }
+    return normalize(d * eta + n * (eta * cosi - sqrtf(k)));
+}
+
+} // namespace rt

@@ -1,0 +1,653 @@
+// rt_gpu.hip — gfx950 kernels of the wavefront pipeline and the C ABI of include/rt_amd.h.
+//
+// One context per GPU (one process per GPU); all work of a render is queued on one HIP stream.
+// Kernel bodies live in rt_pipeline.hpp / rt_core.hpp; this file supplies the launch geometry
+// (256-thread workgroups = 4 wave64, LDS-resident traversal stacks laid out [entry][lane] so a
+// wave's accesses to one stack level are bank-conflict free, grid-stride loops whose item counts
+// are read from device-side queue counters so no host round trip separates the depth levels),
+// the buffers, and the entry points.  There is no CPU fallback behind any entry point.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rt_pipeline.hpp"
+#include "rt_scene.hpp"
+
+using namespace rt;
+
+#define RT_BLOCK 256
+#define RT_MAX_GRID (256 * 8)
+
+// ---- kernels -------------------------------------------------------------------------------------
+template <bool STATS>
+__device__ inline void flush_counters(const Counters& c, unsigned long long* stats, int cls)
+{
+    if (!STATS) return;
+    uint32_t n = c.nodes, t = c.tris, g = c.gates;
+    for (int off = 32; off > 0; off >>= 1) {
+        n += __shfl_xor(n, off); t += __shfl_xor(t, off); g += __shfl_xor(g, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&stats[ST_NODES + cls], (unsigned long long)n);
+        atomicAdd(&stats[ST_TRIS + cls], (unsigned long long)t);
+        atomicAdd(&stats[ST_GATES + cls], (unsigned long long)g);
+    }
+}
+
+__global__ void __launch_bounds__(RT_BLOCK) k_raygen(DScene S, RenderArgs A, Batch B, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) raygen_item(S, A, B, i);
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK) k_trace(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
+{
+    __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_BLOCK];
+    const uint32_t n = depth == 0 ? fixed_n : B.counters[C_QUEUE + depth];
+    Stack st{s_stack + threadIdx.x, RT_BLOCK};
+    Counters cnt{0, 0, 0};
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK)
+        trace_item<STATS>(S, A, B, depth, i, st, cnt);
+    flush_counters<STATS>(cnt, B.stats, 0);
+}
+
+__global__ void __launch_bounds__(RT_BLOCK) k_prep(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
+{
+    const uint32_t n = depth == 0 ? fixed_n : B.counters[C_QUEUE + depth];
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) prep_item(S, A, B, depth, i);
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene S, RenderArgs A, Batch B, int depth)
+{
+    __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_BLOCK];
+    const uint32_t n = B.counters[C_SH + depth];
+    Stack st{s_stack + threadIdx.x, RT_BLOCK};
+    Counters cnt{0, 0, 0};
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK)
+        shadow_item<STATS>(S, A, B, depth, i, st, cnt);
+    flush_counters<STATS>(cnt, B.stats, 1);
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B, int depth)
+{
+    __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_BLOCK];
+    const uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
+    const uint32_t n = B.counters[C_AO + depth] * n2;
+    Stack st{s_stack + threadIdx.x, RT_BLOCK};
+    Counters cnt{0, 0, 0};
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK)
+        ao_item<STATS>(S, A, B, depth, i, st, cnt);
+    flush_counters<STATS>(cnt, B.stats, 2);
+}
+
+__global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
+{
+    const uint32_t n = depth == 0 ? fixed_n : B.counters[C_QUEUE + depth];
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) shade_item(S, A, B, depth, i);
+}
+
+__global__ void __launch_bounds__(RT_BLOCK) k_resolve(DScene S, RenderArgs A, Batch B, uint32_t n, int levels_run)
+{
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) resolve_item(S, A, B, i);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned n2 = (unsigned)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
+        unsigned long long sh = 0, ao = 0, bo = 0;
+        for (int d = 0; d < levels_run; ++d) {
+            sh += B.counters[C_SH + d];
+            ao += (unsigned long long)B.counters[C_AO + d] * n2;
+            if (d > 0) bo += B.counters[C_QUEUE + d];
+        }
+        B.stats[ST_SHADOW] += sh; B.stats[ST_AO] += ao; B.stats[ST_BOUNCE] += bo;
+    }
+}
+
+// slab [tile][RT_TILE*RT_TILE][3] of the tiles owned by (rank, world) -> row-major frame
+__global__ void __launch_bounds__(RT_BLOCK) k_unpack(const float* slab, float* frame, int width, int x0, int y0, int x1, int y1,
+                                                     uint32_t tiles_x, uint32_t tiles_y, int rank, int world, uint32_t owned)
+{
+    const uint32_t n = owned * RT_TILE * RT_TILE;
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
+        uint32_t k = i / (RT_TILE * RT_TILE), l = i % (RT_TILE * RT_TILE);
+        uint32_t tile = (uint32_t)rank + k * (uint32_t)world;
+        uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+        int x = x0 + (int)(tx * RT_TILE + l % RT_TILE), y = y0 + (int)(ty * RT_TILE + l / RT_TILE);
+        if (ty >= tiles_y || x >= x1 || y >= y1) continue;
+        const float* s = slab + (size_t)i * 3;
+        float* o = frame + ((size_t)y * width + x) * 3;
+        o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
+    }
+}
+
+// saveToFile's conversion (reference main.cpp:1847-1849): static_cast<unsigned char>(p * 255)
+__global__ void __launch_bounds__(RT_BLOCK) k_quantize(const float* rgb, uint8_t* out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * RT_BLOCK)
+        out[i] = (uint8_t)(int)(rgb[i] * 255.0f);
+}
+
+// ---- context / scene objects ------------------------------------------------------------------------
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    std::mutex mu;
+    // cached per-render buffers
+    void* batch_mem = nullptr; size_t batch_bytes = 0;
+    unsigned long long* d_stats = nullptr;
+    uint32_t* d_counters = nullptr;
+    float* d_rgb = nullptr; uint32_t* d_prim = nullptr; float* d_t = nullptr; size_t out_pixels = 0;
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+};
+
+struct rt_scene {
+    rt_ctx* ctx = nullptr;
+    HostScene host;
+    bool committed = false;
+    DScene dev{};
+    std::vector<void*> allocs;
+};
+
+static std::string g_init_error;
+
+#define HIPCHECK(ctx, call)                                                                      \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            (ctx)->error = std::string(#call) + ": " + hipGetErrorString(e_);                    \
+            return RT_ERR_HIP;                                                                   \
+        }                                                                                        \
+    } while (0)
+
+static inline uint32_t grid_for(uint64_t n)
+{
+    uint64_t b = (n + RT_BLOCK - 1) / RT_BLOCK;
+    if (b < 1) b = 1;
+    return (uint32_t)(b > RT_MAX_GRID ? RT_MAX_GRID : b);
+}
+
+// ---- HIP launcher backend of render_frame -------------------------------------------------------------
+namespace {
+struct GpuBackend {
+    rt_ctx* ctx; DScene S; Batch B; hipStream_t stream; bool stats; bool timing;
+    int levels_run;
+    struct Span { int cls; size_t e0, e1; };
+    std::vector<Span> spans;
+    size_t ev_used = 0;
+    hipError_t err = hipSuccess;
+
+    size_t ev()
+    {
+        if (ev_used == ctx->ev_pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { err = hipErrorOutOfMemory; return 0; } ctx->ev_pool.push_back(e); }
+        hipEvent_t e = ctx->ev_pool[ev_used];
+        hipError_t r = hipEventRecord(e, stream);
+        if (r != hipSuccess) err = r;
+        return ev_used++;
+    }
+    template <class F> void timed(int cls, F&& f)
+    {
+        size_t a = 0;
+        if (timing) a = ev();
+        f();
+        hipError_t r = hipGetLastError();
+        if (r != hipSuccess) err = r;
+        if (timing) spans.push_back({cls, a, ev()});
+    }
+    void begin_batch(const RenderArgs&)
+    {
+        hipError_t r = hipMemsetAsync(B.counters, 0, sizeof(uint32_t) * C_TOTAL, stream);
+        if (r != hipSuccess) err = r;
+    }
+    void raygen(const RenderArgs& A, uint32_t n) { timed(RT_K_RAYGEN, [&] { hipLaunchKernelGGL(k_raygen, dim3(grid_for(n)), dim3(RT_BLOCK), 0, stream, S, A, B, n); }); }
+    uint32_t grid_d(int d, uint32_t n) { return d == 0 ? grid_for(n) : RT_MAX_GRID; }
+    void trace(const RenderArgs& A, int d, uint32_t n)
+    {
+        timed(RT_K_TRACE, [&] {
+            if (stats) hipLaunchKernelGGL(k_trace<true>, dim3(grid_d(d, n)), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
+            else hipLaunchKernelGGL(k_trace<false>, dim3(grid_d(d, n)), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
+        });
+    }
+    void prep(const RenderArgs& A, int d, uint32_t n) { timed(RT_K_PREP, [&] { hipLaunchKernelGGL(k_prep, dim3(grid_d(d, n)), dim3(RT_BLOCK), 0, stream, S, A, B, d, n); }); }
+    void shadow(const RenderArgs& A, int d)
+    {
+        if (S.num_lights == 0) return;
+        timed(RT_K_SHADOW, [&] {
+            if (stats) hipLaunchKernelGGL(k_shadow<true>, dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, A, B, d);
+            else hipLaunchKernelGGL(k_shadow<false>, dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, A, B, d);
+        });
+    }
+    void ao(const RenderArgs& A, int d)
+    {
+        if (S.ambient.occlusion_samples <= 0) return;
+        timed(RT_K_AO, [&] {
+            if (stats) hipLaunchKernelGGL(k_ao<true>, dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, A, B, d);
+            else hipLaunchKernelGGL(k_ao<false>, dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, A, B, d);
+        });
+    }
+    void shade(const RenderArgs& A, int d, uint32_t n) { timed(RT_K_SHADE, [&] { hipLaunchKernelGGL(k_shade, dim3(grid_d(d, n)), dim3(RT_BLOCK), 0, stream, S, A, B, d, n); }); }
+    void resolve(const RenderArgs& A, uint32_t n) { timed(RT_K_RESOLVE, [&] { hipLaunchKernelGGL(k_resolve, dim3(grid_for(n)), dim3(RT_BLOCK), 0, stream, S, A, B, n, levels_run); }); }
+};
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// carve the per-batch buffers out of one allocation
+size_t carve_batch(Batch& B, char* base, uint32_t P, int levels, uint32_t nl, uint32_t n2)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off = align_up(off + bytes, 256); return p; };
+    B.P = P;
+    for (int k = 0; k < 2; ++k) { B.ray_o[k] = (q4*)take(sizeof(q4) * P); B.ray_d[k] = (q4*)take(sizeof(q4) * P); B.queue[k] = (uint32_t*)take(4ull * P); }
+    B.hit = (q4*)take(sizeof(q4) * P);
+    B.nrm = (q4*)take(sizeof(q4) * P);
+    B.pstate = (uint32_t*)take(4ull * P);
+    B.ao_queue = (uint32_t*)take(4ull * P);
+    B.ao_slot = (uint32_t*)take(4ull * P);
+    B.sh_queue = (uint32_t*)take(4ull * P * nl);
+    B.ao_t = (float*)take(4ull * P * (n2 ? n2 : 1));
+    B.sh_res = (float*)take(4ull * P * nl);
+    B.lvl = (q4*)take(sizeof(q4) * (size_t)P * levels);
+    B.lvl_ph = (float*)take(4ull * P * levels * (nl > 1 ? nl - 1 : 1));
+    B.lvl_kind = (uint8_t*)take((size_t)P * levels);
+    return off;
+}
+} // namespace
+
+// ---- C ABI ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int rt_version(void) { return RT_AMD_VERSION; }
+
+void rt_params_default(rt_params* p)
+{
+    if (!p) return;
+    std::memset(p, 0, sizeof *p);
+    p->width = 1000; p->height = 1000; p->x1 = 1000; p->y1 = 1000;
+    p->num_samples = 4; p->num_sets = 83; p->sampler = RT_SAMPLER_JITTER;
+    p->max_depth = 3; p->light_attenuation = 500000.0f; p->seed = 1;
+    p->tile_rank = 0; p->tile_world = 1;
+}
+
+const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_init_error.c_str(); }
+
+int rt_init(int device, rt_ctx** out)
+{
+    if (!out) { g_init_error = "rt_init: null out pointer"; return RT_ERR_INVALID; }
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) { g_init_error = std::string("rt_init: no HIP device (") + hipGetErrorString(e) + "); this library has no CPU fallback"; return RT_ERR_HIP; }
+    if (device < 0 || device >= count) { g_init_error = "rt_init: device index out of range"; return RT_ERR_INVALID; }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { g_init_error = hipGetErrorString(e); return RT_ERR_HIP; }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { g_init_error = std::string("rt_init: kernels are built for gfx950 only, device is ") + prop.gcnArchName; return RT_ERR_HIP; }
+    if ((e = hipSetDevice(device)) != hipSuccess) { g_init_error = hipGetErrorString(e); return RT_ERR_HIP; }
+    rt_ctx* c = new (std::nothrow) rt_ctx();
+    if (!c) return RT_ERR_NOMEM;
+    c->device = device;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipMalloc((void**)&c->d_stats, sizeof(unsigned long long) * ST_TOTAL)) != hipSuccess ||
+        (e = hipMalloc((void**)&c->d_counters, sizeof(uint32_t) * C_TOTAL)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev_begin)) != hipSuccess || (e = hipEventCreate(&c->ev_end)) != hipSuccess) {
+        g_init_error = std::string("rt_init: ") + hipGetErrorString(e);
+        delete c;
+        return RT_ERR_HIP;
+    }
+    *out = c;
+    return RT_OK;
+}
+
+int rt_shutdown(rt_ctx* c)
+{
+    if (!c) return RT_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+    if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    (void)hipFree(c->batch_mem); (void)hipFree(c->d_stats); (void)hipFree(c->d_counters);
+    (void)hipFree(c->d_rgb); (void)hipFree(c->d_prim); (void)hipFree(c->d_t);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return RT_OK;
+}
+
+int rt_scene_create(rt_ctx* ctx, rt_scene** out)
+{
+    if (!ctx || !out) return RT_ERR_INVALID;
+    rt_scene* s = new (std::nothrow) rt_scene();
+    if (!s) return RT_ERR_NOMEM;
+    s->ctx = ctx;
+    s->host.ambient = rt_ambient{{1.0f, 1.0f, 1.0f}, 0.0f, 0, 1000.0f};
+    *out = s;
+    return RT_OK;
+}
+
+#define RT_SETTER(name, type, field)                                                     \
+    int rt_scene_set_##name(rt_scene* s, const type* v, size_t n)                        \
+    {                                                                                    \
+        if (!s || (n && !v)) return RT_ERR_INVALID;                                      \
+        s->host.field.assign(v, v + n);                                                  \
+        s->committed = false;                                                            \
+        return RT_OK;                                                                    \
+    }
+RT_SETTER(planes, rt_plane, planes)
+RT_SETTER(spheres, rt_sphere, spheres)
+RT_SETTER(triangles, rt_triangle, triangles)
+RT_SETTER(meshes, rt_mesh, meshes)
+RT_SETTER(multimeshes, rt_multimesh, multimeshes)
+RT_SETTER(scene, rt_shape_ref, scene)
+RT_SETTER(materials, rt_material, materials)
+RT_SETTER(lights, rt_light, lights)
+
+int rt_scene_set_bvhs(rt_scene* s, const rt_bvh* v, size_t n, const rt_shape_ref* leaves, size_t num_leaves)
+{
+    if (!s || (n && !v) || (num_leaves && !leaves)) return RT_ERR_INVALID;
+    s->host.bvhs.assign(v, v + n);
+    s->host.bvh_leaves.assign(leaves, leaves + num_leaves);
+    s->committed = false;
+    return RT_OK;
+}
+
+int rt_scene_set_textures(rt_scene* s, const rt_texture* v, size_t n)
+{
+    if (!s || (n && !v)) return RT_ERR_INVALID;
+    s->host.textures.assign(v, v + n);
+    s->host.texel_store.assign(n, {});
+    for (size_t i = 0; i < n; ++i) {
+        if (v[i].rgba && v[i].width > 0 && v[i].height > 0) {
+            s->host.texel_store[i].assign(v[i].rgba, v[i].rgba + (size_t)v[i].width * v[i].height * 4);
+            s->host.textures[i].rgba = s->host.texel_store[i].data();
+        } else s->host.textures[i].rgba = nullptr;
+    }
+    s->committed = false;
+    return RT_OK;
+}
+
+int rt_scene_set_ambient(rt_scene* s, const rt_ambient* a)
+{
+    if (!s || !a) return RT_ERR_INVALID;
+    s->host.ambient = *a;
+    s->committed = false;
+    return RT_OK;
+}
+
+int rt_scene_set_desc(rt_scene* s, const rt_scene_desc* d)
+{
+    if (!s || !d) return RT_ERR_INVALID;
+    int rc;
+    if ((rc = rt_scene_set_planes(s, d->planes, d->num_planes))) return rc;
+    if ((rc = rt_scene_set_spheres(s, d->spheres, d->num_spheres))) return rc;
+    if ((rc = rt_scene_set_triangles(s, d->triangles, d->num_triangles))) return rc;
+    if ((rc = rt_scene_set_meshes(s, d->meshes, d->num_meshes))) return rc;
+    if ((rc = rt_scene_set_multimeshes(s, d->multimeshes, d->num_multimeshes))) return rc;
+    if ((rc = rt_scene_set_bvhs(s, d->bvhs, d->num_bvhs, d->bvh_leaves, d->num_bvh_leaves))) return rc;
+    if ((rc = rt_scene_set_scene(s, d->scene, d->num_scene))) return rc;
+    if ((rc = rt_scene_set_materials(s, d->materials, d->num_materials))) return rc;
+    if ((rc = rt_scene_set_textures(s, d->textures, d->num_textures))) return rc;
+    if ((rc = rt_scene_set_lights(s, d->lights, d->num_lights))) return rc;
+    return rt_scene_set_ambient(s, &d->ambient);
+}
+
+static void scene_free_device(rt_scene* s)
+{
+    for (void* p : s->allocs) (void)hipFree(p);
+    s->allocs.clear();
+    s->dev = DScene{};
+}
+
+int rt_scene_commit(rt_scene* s)
+{
+    if (!s) return RT_ERR_INVALID;
+    rt_ctx* ctx = s->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHECK(ctx, hipSetDevice(ctx->device));
+    int rc = s->host.build();
+    if (rc) { ctx->error = "rt_scene_commit: " + s->host.error; return rc; }
+    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    scene_free_device(s);
+    HostScene& H = s->host;
+    auto up = [&](const void* src, size_t bytes, const void** dst) -> int {
+        void* d = nullptr;
+        size_t b = bytes ? bytes : 16;
+        HIPCHECK(ctx, hipMalloc(&d, b));
+        s->allocs.push_back(d);
+        if (bytes) HIPCHECK(ctx, hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+        *dst = d;
+        return RT_OK;
+    };
+    DScene& D = s->dev;
+    if ((rc = up(H.gates.data(), H.gates.size() * sizeof(GateNode), (const void**)&D.gates))) return rc;
+    if ((rc = up(H.planes4.data(), H.planes4.size() * sizeof(q4), (const void**)&D.planes))) return rc;
+    if ((rc = up(H.spheres4.data(), H.spheres4.size() * sizeof(q4), (const void**)&D.spheres))) return rc;
+    if ((rc = up(H.tris4.data(), H.tris4.size() * sizeof(q4), (const void**)&D.tris))) return rc;
+    if ((rc = up(H.attr4.data(), H.attr4.size() * sizeof(q4), (const void**)&D.tri_attr))) return rc;
+    if ((rc = up(H.nodes4.data(), H.nodes4.size() * sizeof(q4), (const void**)&D.nodes))) return rc;
+    if ((rc = up(H.dmaterials.data(), H.dmaterials.size() * sizeof(DMaterial), (const void**)&D.materials))) return rc;
+    if ((rc = up(H.dlights.data(), H.dlights.size() * sizeof(DLight), (const void**)&D.lights))) return rc;
+    if ((rc = up(H.dtextures.data(), H.dtextures.size() * sizeof(DTexture), (const void**)&D.textures))) return rc;
+    if ((rc = up(H.texels.data(), H.texels.size(), (const void**)&D.texels))) return rc;
+    if ((rc = up(H.item_opaque.data(), H.item_opaque.size(), (const void**)&D.item_opaque))) return rc;
+    D.num_gates = (uint32_t)H.gates.size();
+    D.num_lights = (uint32_t)H.dlights.size();
+    D.num_textures = (uint32_t)H.dtextures.size();
+    D.num_items = (uint32_t)H.item_opaque.size();
+    D.ambient = H.ambient;
+    D.prim_base_sphere = (uint32_t)H.planes.size();
+    D.prim_base_tri = (uint32_t)(H.planes.size() + H.spheres.size());
+    D.cull_pad = 1.0f / 262144.0f;
+    D.extent = H.extent;
+    s->committed = true;
+    return RT_OK;
+}
+
+int rt_scene_destroy(rt_scene* s)
+{
+    if (!s) return RT_ERR_INVALID;
+    {
+        std::lock_guard<std::mutex> lk(s->ctx->mu);
+        (void)hipSetDevice(s->ctx->device);
+        (void)hipStreamSynchronize(s->ctx->stream);
+        scene_free_device(s);
+    }
+    delete s;
+    return RT_OK;
+}
+
+static int check_params(rt_ctx* ctx, const rt_params* p)
+{
+    auto bad = [&](const char* m) { ctx->error = std::string("rt_render: ") + m; return (int)RT_ERR_INVALID; };
+    if (p->width <= 0 || p->height <= 0) return bad("image size must be positive");
+    if (p->x0 < 0 || p->y0 < 0 || p->x1 > p->width || p->y1 > p->height || p->x0 > p->x1 || p->y0 > p->y1) return bad("render rectangle outside the image");
+    if (p->num_samples <= 0 || p->num_samples > 65536) return bad("num_samples out of range");
+    if (p->sampler < RT_SAMPLER_REGULAR || p->sampler > RT_SAMPLER_RANDOM) return bad("unknown sampler");
+    if (p->max_depth < 0 || p->max_depth + 2 > RT_MAX_LEVELS) return bad("max_depth out of range [0,60]");
+    if (p->tile_world < 1 || p->tile_rank < 0 || p->tile_rank >= p->tile_world) return bad("tile_rank/tile_world inconsistent");
+    if ((uint64_t)p->width * p->height > 0xFFFFFFFFull) return bad("image too large");
+    return RT_OK;
+}
+
+static void tile_grid(const rt_params* p, uint32_t& tx, uint32_t& ty)
+{
+    tx = (uint32_t)((p->x1 - p->x0 + RT_TILE - 1) / RT_TILE);
+    ty = (uint32_t)((p->y1 - p->y0 + RT_TILE - 1) / RT_TILE);
+}
+
+int rt_owned_tiles(const rt_params* p, int rank, int world, uint32_t* out)
+{
+    if (!p || !out || world < 1 || rank < 0 || rank >= world) return RT_ERR_INVALID;
+    uint32_t tx, ty;
+    tile_grid(p, tx, ty);
+    uint32_t total = tx * ty;
+    *out = total > (uint32_t)rank ? (total - (uint32_t)rank + (uint32_t)world - 1) / (uint32_t)world : 0;
+    return RT_OK;
+}
+
+static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, float* d_rgb, uint32_t* d_prim,
+                         float* d_t, rt_stats* stats, hipStream_t stream, bool slab, bool wait)
+{
+    rt_ctx* ctx = s->ctx;
+    const DScene& S = s->dev;
+    RenderArgs A{};
+    A.cam = make_camera(*cam);
+    A.width = p->width; A.height = p->height; A.x0 = p->x0; A.y0 = p->y0; A.x1 = p->x1; A.y1 = p->y1;
+    A.spp = p->num_samples; A.sampler = p->sampler; A.max_depth = p->max_depth; A.levels = p->max_depth + 2;
+    A.light_atten = p->light_attenuation; A.seed = p->seed;
+    tile_grid(p, A.tiles_x, A.tiles_y);
+    A.tile_rank = p->tile_rank; A.tile_world = p->tile_world;
+    A.out_rgb = d_rgb; A.out_prim = d_prim; A.out_t = d_t; A.slab = slab ? 1 : 0;
+    uint32_t owned = 0;
+    rt_owned_tiles(p, p->tile_rank, p->tile_world, &owned);
+
+    const bool bounces = s->host.has_bounce_materials;
+    const int levels_alloc = bounces ? A.levels : 1;
+    const uint64_t per_tile = (uint64_t)RT_TILE * RT_TILE * (uint64_t)A.spp;
+    uint64_t want = p->batch_paths ? p->batch_paths : (4u << 20);
+    uint32_t tiles_per_batch = (uint32_t)(want / per_tile);
+    if (tiles_per_batch < 1) tiles_per_batch = 1;
+    if (tiles_per_batch > owned && owned > 0) tiles_per_batch = owned;
+    if ((uint64_t)tiles_per_batch * per_tile > 0x7FFFFFFFull) { ctx->error = "rt_render: one tile x num_samples exceeds 2^31 paths"; return RT_ERR_UNSUPPORTED; }
+    const uint32_t P = (uint32_t)(tiles_per_batch * per_tile);
+    const uint32_t nl = S.num_lights ? S.num_lights : 1;
+    const uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
+    if ((uint64_t)P * nl > 0xFFFFFFFFull || (uint64_t)P * (n2 ? n2 : 1) > 0xFFFFFFFFull) { ctx->error = "rt_render: batch too large for 32-bit queue entries; lower batch_paths"; return RT_ERR_UNSUPPORTED; }
+
+    Batch B{};
+    size_t need = carve_batch(B, nullptr, P, levels_alloc, nl, n2);
+    if (need > ctx->batch_bytes) {
+        HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->batch_mem) HIPCHECK(ctx, hipFree(ctx->batch_mem));
+        ctx->batch_mem = nullptr; ctx->batch_bytes = 0;
+        HIPCHECK(ctx, hipMalloc(&ctx->batch_mem, need));
+        ctx->batch_bytes = need;
+    }
+    carve_batch(B, (char*)ctx->batch_mem, P, levels_alloc, nl, n2);
+    B.counters = ctx->d_counters;
+    B.stats = ctx->d_stats;
+
+    GpuBackend be{ctx, S, B, stream, (p->flags & RT_FLAG_STATS) != 0, (p->flags & RT_FLAG_TIMING) != 0, levels_alloc};
+    HIPCHECK(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * ST_TOTAL, stream));
+    HIPCHECK(ctx, hipEventRecord(ctx->ev_begin, stream));
+    uint32_t batches = 0;
+    if (owned > 0 && p->x1 > p->x0 && p->y1 > p->y0) {
+        render_frame(be, A, owned, tiles_per_batch, bounces);
+        batches = (owned + tiles_per_batch - 1) / tiles_per_batch;
+    }
+    HIPCHECK(ctx, hipEventRecord(ctx->ev_end, stream));
+    if (be.err != hipSuccess) { ctx->error = std::string("rt_render: launch failed: ") + hipGetErrorString(be.err); return RT_ERR_HIP; }
+    if (!wait && !stats) return RT_OK;
+    HIPCHECK(ctx, hipStreamSynchronize(stream));
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        unsigned long long h[ST_TOTAL];
+        HIPCHECK(ctx, hipMemcpy(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost));
+        // primary rays: valid pixels of the owned tiles x spp
+        uint64_t prim = 0;
+        for (uint32_t k = 0; k < owned; ++k) {
+            uint32_t tile = (uint32_t)p->tile_rank + k * (uint32_t)p->tile_world;
+            uint32_t tx = tile % A.tiles_x, ty = tile / A.tiles_x;
+            int w = std::min(RT_TILE, p->x1 - p->x0 - (int)tx * RT_TILE), hh = std::min(RT_TILE, p->y1 - p->y0 - (int)ty * RT_TILE);
+            if (w > 0 && hh > 0) prim += (uint64_t)w * hh;
+        }
+        stats->rays_primary = prim * (uint64_t)A.spp;
+        stats->rays_shadow = h[ST_SHADOW]; stats->rays_ao = h[ST_AO]; stats->rays_bounce = h[ST_BOUNCE];
+        for (int k = 0; k < 3; ++k) { stats->nodes[k] = h[ST_NODES + k]; stats->tris[k] = h[ST_TRIS + k]; stats->gates[k] = h[ST_GATES + k]; }
+        float ms = 0.0f;
+        HIPCHECK(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+        stats->ms_total = ms;
+        stats->batches = batches;
+        for (auto& sp : be.spans) {
+            float m = 0.0f;
+            HIPCHECK(ctx, hipEventElapsedTime(&m, ctx->ev_pool[sp.e0], ctx->ev_pool[sp.e1]));
+            stats->ms_kernel[sp.cls] += m;
+            stats->launches[sp.cls]++;
+        }
+    }
+    return RT_OK;
+}
+
+int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* p, float* d_rgb, uint32_t* d_primid,
+                     float* d_t, rt_stats* stats, void* stream)
+{
+    if (!s || !cam || !p || !d_rgb) return RT_ERR_INVALID;
+    rt_ctx* ctx = s->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!s->committed) { ctx->error = "rt_render: scene not committed"; return RT_ERR_STATE; }
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    HIPCHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    return render_locked(s, cam, p, d_rgb, d_primid, d_t, stats, st, p->tile_world > 1, stream == nullptr);
+}
+
+int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* p, float* rgb, uint32_t* primid, float* t, rt_stats* stats)
+{
+    if (!s || !cam || !p) return RT_ERR_INVALID;
+    rt_ctx* ctx = s->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!s->committed) { ctx->error = "rt_render: scene not committed"; return RT_ERR_STATE; }
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    HIPCHECK(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)p->width * p->height;
+    if (npix > ctx->out_pixels) {
+        HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_rgb); (void)hipFree(ctx->d_prim); (void)hipFree(ctx->d_t);
+        ctx->d_rgb = nullptr; ctx->d_prim = nullptr; ctx->d_t = nullptr; ctx->out_pixels = 0;
+        HIPCHECK(ctx, hipMalloc((void**)&ctx->d_rgb, npix * 12));
+        HIPCHECK(ctx, hipMalloc((void**)&ctx->d_prim, npix * 4));
+        HIPCHECK(ctx, hipMalloc((void**)&ctx->d_t, npix * 4));
+        ctx->out_pixels = npix;
+    }
+    const bool partial = p->x0 != 0 || p->y0 != 0 || p->x1 != p->width || p->y1 != p->height || p->tile_world > 1;
+    if (partial) {   // keep what the caller has outside the rendered pixels
+        if (rgb) HIPCHECK(ctx, hipMemcpyAsync(ctx->d_rgb, rgb, npix * 12, hipMemcpyHostToDevice, ctx->stream));
+        if (primid) HIPCHECK(ctx, hipMemcpyAsync(ctx->d_prim, primid, npix * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (t) HIPCHECK(ctx, hipMemcpyAsync(ctx->d_t, t, npix * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    rc = render_locked(s, cam, p, ctx->d_rgb, primid ? ctx->d_prim : nullptr, t ? ctx->d_t : nullptr, stats, ctx->stream, false, true);
+    if (rc) return rc;
+    if (rgb) HIPCHECK(ctx, hipMemcpy(rgb, ctx->d_rgb, npix * 12, hipMemcpyDeviceToHost));
+    if (primid) HIPCHECK(ctx, hipMemcpy(primid, ctx->d_prim, npix * 4, hipMemcpyDeviceToHost));
+    if (t) HIPCHECK(ctx, hipMemcpy(t, ctx->d_t, npix * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_unpack_tiles(rt_ctx* ctx, const float* d_slab, const rt_params* p, int rank, int world, float* d_frame, void* stream)
+{
+    if (!ctx || !d_slab || !p || !d_frame) return RT_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    uint32_t owned = 0;
+    if (rt_owned_tiles(p, rank, world, &owned) != RT_OK) { ctx->error = "rt_unpack_tiles: bad rank/world"; return RT_ERR_INVALID; }
+    if (owned == 0) return RT_OK;
+    HIPCHECK(ctx, hipSetDevice(ctx->device));
+    uint32_t tx, ty;
+    tile_grid(p, tx, ty);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    hipLaunchKernelGGL(k_unpack, dim3(grid_for((uint64_t)owned * RT_TILE * RT_TILE)), dim3(RT_BLOCK), 0, st,
+                       d_slab, d_frame, p->width, p->x0, p->y0, p->x1, p->y1, tx, ty, rank, world, owned);
+    HIPCHECK(ctx, hipGetLastError());
+    if (!stream) HIPCHECK(ctx, hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+int rt_quantize_rgb8(rt_ctx* ctx, const float* d_rgb, size_t num_pixels, uint8_t* d_rgb8, void* stream)
+{
+    if (!ctx || !d_rgb || !d_rgb8) return RT_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (num_pixels) hipLaunchKernelGGL(k_quantize, dim3(grid_for(num_pixels * 3)), dim3(RT_BLOCK), 0, st, d_rgb, d_rgb8, num_pixels * 3);
+    HIPCHECK(ctx, hipGetLastError());
+    if (!stream) HIPCHECK(ctx, hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,398 @@
+// rt_pipeline.hpp — the wavefront pipeline: per-item bodies of the seven kernels and the
+// batch/depth loop that sequences them.  The item bodies are host/device functions (see
+// rt_core.hpp for why); `render_frame<Backend>` is instantiated with the HIP launcher in
+// rt_api.cpp and with a sequential loop backend in the test-only emulation (tests/emul/).
+//
+// Pipeline per batch of P = pixels*spp paths (reference call stack in brackets):
+//   raygen            [raytrace(): sampleUnitSquare + Camera::calculateRay, main.cpp:1633-1641]
+//   for depth d = 0 .. max_depth+1 over the per-depth path queue:
+//     trace           [for obj in world->scene: obj->hit(), main.cpp:1645-1648 / 1457-1460 / 1548-1551]
+//     prep            [hit attributes; Reflective::rho / Transparency::rho ray set-up, main.cpp:1437-1468, 1525-1592]
+//     shadow          [Material::shadowed, main.cpp:40-76]
+//     ao              [Ambient::L's n x n rays, main.cpp:1361-1404]
+//     shade           [Matte/Specular/Textured/Mirror/Refraction::shade, main.cpp:1143-1299, 1487-1511, 1607-1616]
+//   resolve           [per-level `L = clamp(local + child)` unwound deepest first; pixel average main.cpp:1656-1658]
+#pragma once
+#include "rt_core.hpp"
+
+namespace rt {
+
+enum : uint8_t { LK_NONE = 0, LK_TERMINAL = 1, LK_MIRROR = 2, LK_REFRACT = 3 };
+enum { C_QUEUE = 0, C_AO = 64, C_SH = 128, C_TOTAL = 192 };          // per-batch u32 counters
+enum { ST_SHADOW = 0, ST_AO = 1, ST_BOUNCE = 2, ST_NODES = 3, ST_TRIS = 6, ST_GATES = 9, ST_TOTAL = 12 }; // u64
+#define RT_MAX_LEVELS 62
+
+struct Batch {
+    uint32_t P;            // path capacity of the buffers
+    q4* ray_o[2];          // {origin, index of refraction of the medium (ShadeRec::indexOfRefraction)}
+    q4* ray_d[2];          // {direction, 0}
+    q4* hit;               // {t, bits(prim), u, v}  (u,v: barycentric after trace, texture uv after prep)
+    q4* nrm;               // {normal, bits(material)}
+    uint32_t* pstate;      // bits 0..7: Ambient::L evaluations so far; bits 8..15: index of the current one
+    uint32_t* queue[2];    // paths alive at depth d (d >= 1), ping-pong
+    uint32_t* ao_queue;    // paths whose ambient term needs occlusion rays at this depth
+    uint32_t* ao_slot;     // per path: its position in ao_queue, 0xFFFFFFFF = none
+    uint32_t* sh_queue;    // p * num_lights + light
+    float* ao_t;           // [slot * n*n + k]  closest distance (occlusion_dist when nothing was hit)
+    float* sh_res;         // [p * num_lights + light]
+    q4* lvl;               // [d*P + p]  TERMINAL: final colour; MIRROR: {ambient term, phong of light 0}
+    float* lvl_ph;         // [(d*P + p)*(num_lights-1) + (l-1)] phong of lights 1..
+    uint8_t* lvl_kind;     // [d*P + p]
+    uint32_t* counters;    // C_TOTAL
+    unsigned long long* stats; // ST_TOTAL, accumulated over the whole render
+};
+
+struct RenderArgs {
+    DCamera cam;
+    int32_t width, height, x0, y0, x1, y1;
+    int32_t spp, sampler, max_depth, levels;   // levels = max_depth + 2
+    float light_atten;
+    uint32_t seed;
+    uint32_t tiles_x, tiles_y;                 // RT_TILE tiles covering the render rectangle
+    int32_t tile_rank, tile_world;
+    uint32_t first_tile, num_tiles;            // this batch: owned-tile ordinals [first_tile, first_tile+num_tiles)
+    uint32_t npx;                              // num_tiles * RT_TILE*RT_TILE
+    float* out_rgb; uint32_t* out_prim; float* out_t;
+    int32_t slab;                              // 1: outputs are compact tile slabs, 0: full frames
+};
+
+// path p -> (pixel, sample); paths are sample-major so a wave covers an 8x8 pixel block
+struct PathPix { int x, y; uint32_t j, q; bool valid; uint32_t key; size_t out; };
+
+RT_FN PathPix pix_of(const RenderArgs& A, uint32_t q)
+{
+    PathPix r; r.q = q; r.j = 0;
+    uint32_t slot = q / (RT_TILE * RT_TILE), local = q % (RT_TILE * RT_TILE);
+    uint32_t tile = (uint32_t)A.tile_rank + (A.first_tile + slot) * (uint32_t)A.tile_world;
+    uint32_t tx = tile % A.tiles_x, ty = tile / A.tiles_x;
+    uint32_t mt = local / 64, l = local % 64;
+    uint32_t lx = (mt % 8) * 8 + (l % 8), ly = (mt / 8) * 8 + (l / 8);
+    r.x = A.x0 + (int)(tx * RT_TILE + lx);
+    r.y = A.y0 + (int)(ty * RT_TILE + ly);
+    r.valid = ty < A.tiles_y && r.x < A.x1 && r.y < A.y1;
+    r.key = (uint32_t)(r.y * A.width + r.x);
+    r.out = A.slab ? ((size_t)(A.first_tile + slot) * (RT_TILE * RT_TILE) + ly * RT_TILE + lx)
+                   : ((size_t)r.y * (size_t)A.width + (size_t)r.x);
+    return r;
+}
+RT_FN PathPix path_of(const RenderArgs& A, uint32_t p)
+{
+    PathPix r = pix_of(A, p % A.npx);
+    r.j = p / A.npx;
+    return r;
+}
+
+// queue append; on the GPU this is specialised with a wave ballot + one atomic per wave
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline uint32_t queue_slot(uint32_t* counter)
+{
+    unsigned long long mask = __ballot(1);
+    uint32_t lane = __lane_id();
+    uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+#else
+inline uint32_t queue_slot(uint32_t* counter) { return (*counter)++; }
+#endif
+
+// ---- kernel bodies --------------------------------------------------------------------------------
+RT_FN void raygen_item(const DScene& S, const RenderArgs& A, const Batch& B, uint32_t p)
+{
+    PathPix px = path_of(A, p);
+    B.pstate[p] = 0;
+    if (!px.valid) { B.lvl_kind[p] = LK_NONE; return; }
+    float sx, sy;
+    sample_point(A.sampler, A.spp, A.seed, px.key, (int)px.j, sx, sy);
+    float fx = ((float)px.x - (0.5f * (float)A.width)) + sx;   // main.cpp:1639-1640
+    float fy = ((float)px.y - (0.5f * (float)A.height)) + sy;
+    f3 d = camera_dir(A.cam, fx, fy);
+    q4 o4 = {A.cam.eye.x, A.cam.eye.y, A.cam.eye.z, 1.0f};
+    q4 d4 = {d.x, d.y, d.z, 0.0f};
+    B.ray_o[0][p] = o4; B.ray_d[0][p] = d4;
+}
+
+RT_FN uint32_t item_path(const RenderArgs& A, const Batch& B, int depth, uint32_t idx)
+{
+    return depth == 0 ? idx : B.queue[depth & 1][idx];
+}
+
+template <bool STATS>
+RT_FN void trace_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, Stack st, Counters& cnt)
+{
+    uint32_t p = item_path(A, B, depth, idx);
+    if (depth == 0 && !path_of(A, p).valid) return;
+    q4 o4 = B.ray_o[depth & 1][p], d4 = B.ray_d[depth & 1][p];
+    Hit h; float sh;
+    trace<0, STATS>(S, xyz(o4), xyz(d4), FLT_MAX, h, sh, st, cnt);
+    q4 r = {h.t, u2f(h.prim), h.u, h.v};
+    B.hit[p] = r;
+}
+
+RT_FN void prep_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx)
+{
+    uint32_t p = item_path(A, B, depth, idx);
+    PathPix px = path_of(A, p);
+    if (depth == 0 && !px.valid) return;
+    q4 h4 = B.hit[p];
+    Hit h; h.t = h4.x; h.prim = f2u(h4.y); h.u = h4.z; h.v = h4.w;
+    size_t li = (size_t)depth * B.P + p;
+    q4 o4 = B.ray_o[depth & 1][p], d4 = B.ray_d[depth & 1][p];
+    f3 o = xyz(o4), d = xyz(d4);
+    if (h.prim == H_MISS) {
+        B.lvl_kind[li] = LK_NONE;
+        if (depth == 0 && px.j == 0) {
+            if (A.out_prim) A.out_prim[px.out] = 0xFFFFFFFFu;
+            if (A.out_t) A.out_t[px.out] = h.t;
+        }
+        return;
+    }
+    Surface sf = surface_of(S, h, o, d);
+    if (depth == 0 && px.j == 0) {
+        if (A.out_prim) A.out_prim[px.out] = sf.prim_id;
+        if (A.out_t) A.out_t[px.out] = h.t;
+    }
+    q4 n4 = {sf.normal.x, sf.normal.y, sf.normal.z, u2f((uint32_t)sf.material)};
+    B.nrm[p] = n4;
+    h4.z = sf.u; h4.w = sf.v;
+    B.hit[p] = h4;
+    const DMaterial M = S.materials[sf.material];
+    f3 P = o + d * h.t;   // sr.ray(sr.t) = o + t*d
+
+    // ambient term: every class but Refraction evaluates world->ambient->L(sr)
+    uint32_t ps = B.pstate[p];
+    uint32_t slot = 0xFFFFFFFFu;
+    if (M.kind != RT_MAT_REFRACTION && S.ambient.occlusion_samples > 0) {
+        uint32_t a = ps & 0xFFu;
+        ps = ((a + 1u) & 0xFFu) | (a << 8);
+        B.pstate[p] = ps;
+        if (M.ka != 0.0f) {   // ka == 0 multiplies the (finite) occlusion factor away: no rays needed
+            slot = queue_slot(&B.counters[C_AO + depth]);
+            B.ao_queue[slot] = p;
+        }
+    }
+    B.ao_slot[p] = slot;
+
+    if (M.kind == RT_MAT_SPECULAR || M.kind == RT_MAT_TEXTURED) {
+        // the shadow ray is only consumed when n.wi > 0 (main.cpp:1227-1237, 1281-1293)
+        for (uint32_t l = 0; l < S.num_lights; ++l) {
+            f3 wi = normalize(light_direction(S.lights[l], P));
+            if (dot(sf.normal, wi) > 0.0f) {
+                uint32_t e = queue_slot(&B.counters[C_SH + depth]);
+                B.sh_queue[e] = p * S.num_lights + l;
+            }
+        }
+    }
+
+    if (M.kind == RT_MAT_MIRROR || M.kind == RT_MAT_REFRACTION) {
+        B.lvl_kind[li] = M.kind == RT_MAT_MIRROR ? LK_MIRROR : LK_REFRACT;
+        if (depth + 1 < A.levels) B.lvl_kind[li + B.P] = LK_NONE;
+        if (!((unsigned)depth > (unsigned)A.max_depth)) {   // `if (sr.depth > maxBounceDepth) return sr.color`
+            f3 r; float ior = 1.0f;
+            if (M.kind == RT_MAT_MIRROR) {
+                f3 wo = normalize(-d);
+                r = reflect(-wo, sf.normal);
+            } else {
+                float enter = M.ior;
+                r = refraction_dir(d, sf.normal, o4.w, enter);
+                ior = enter;
+            }
+            f3 no = (o + d * h.t) + r * 0.1f;
+            q4 no4 = {no.x, no.y, no.z, ior};
+            q4 nd4 = {r.x, r.y, r.z, 0.0f};
+            B.ray_o[(depth + 1) & 1][p] = no4; B.ray_d[(depth + 1) & 1][p] = nd4;
+            uint32_t e = queue_slot(&B.counters[C_QUEUE + depth + 1]);
+            B.queue[(depth + 1) & 1][e] = p;
+        }
+    } else {
+        B.lvl_kind[li] = LK_TERMINAL;
+    }
+}
+
+template <bool STATS>
+RT_FN void shadow_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, Stack st, Counters& cnt)
+{
+    uint32_t e = B.sh_queue[idx];
+    uint32_t p = e / S.num_lights, l = e % S.num_lights;
+    q4 o4 = B.ray_o[depth & 1][p], d4 = B.ray_d[depth & 1][p];
+    f3 P = xyz(o4) + xyz(d4) * B.hit[p].x;
+    f3 src = light_source(S.lights[l], P);
+    f3 dir = normalize(P - src);
+    float dist = length(P - src) - 0.01f;
+    Hit h; float sh = 1.0f;
+    trace<1, STATS>(S, src, dir, dist, h, sh, st, cnt);
+    B.sh_res[e] = sh;
+}
+
+template <bool STATS>
+RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, Stack st, Counters& cnt)
+{
+    uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
+    uint32_t slot = idx / n2, k = idx % n2;
+    uint32_t p = B.ao_queue[slot];
+    PathPix px = path_of(A, p);
+    q4 o4 = B.ray_o[depth & 1][p], d4 = B.ray_d[depth & 1][p];
+    f3 P = xyz(o4) + xyz(d4) * B.hit[p].x;
+    f3 N = xyz(B.nrm[p]);
+    uint32_t a = (B.pstate[p] >> 8) & 0xFFu;
+    f3 o, dir;
+    ao_ray(S.ambient, P, N, A.seed, px.key, px.j, a, k, o, dir);
+    Hit h; float sh;
+    trace<0, STATS>(S, o, dir, S.ambient.occlusion_dist, h, sh, st, cnt);
+    B.ao_t[idx] = h.t;   // stays occlusion_dist when nothing closer was found
+}
+
+// world->ambient->L(sr): Light::L, or Ambient::L's reduction of the n*n distances in x,y order
+RT_FN f3 ambient_L(const DScene& S, const Batch& B, uint32_t p)
+{
+    const rt_ambient& A = S.ambient;
+    f3 base = F3(A.colour[0], A.colour[1], A.colour[2]) * A.radiance;
+    if (A.occlusion_samples <= 0) return base;
+    uint32_t slot = B.ao_slot[p];
+    if (slot == 0xFFFFFFFFu) return base;
+    unsigned n = (unsigned)A.occlusion_samples;
+    float dist = A.occlusion_dist;
+    float maxSum = (dist * (float)n * (float)n);
+    float occluded = maxSum;
+    const float* t = B.ao_t + (size_t)slot * n * n;
+    for (unsigned k = 0; k < n * n; ++k) occluded -= (dist - t[k]);
+    float f = occluded / maxSum;
+    return base * f * f;
+}
+
+RT_FN void shade_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx)
+{
+    uint32_t p = item_path(A, B, depth, idx);
+    if (depth == 0 && !path_of(A, p).valid) return;
+    q4 h4 = B.hit[p];
+    if (f2u(h4.y) == H_MISS) return;
+    size_t li = (size_t)depth * B.P + p;
+    q4 n4 = B.nrm[p];
+    f3 N = xyz(n4);
+    const DMaterial M = S.materials[f2u(n4.w)];
+    if (M.kind == RT_MAT_REFRACTION) return;   // Refraction::shade = clamp(child): nothing local
+    q4 o4 = B.ray_o[depth & 1][p], d4 = B.ray_d[depth & 1][p];
+    f3 o = xyz(o4), d = xyz(d4);
+    f3 P = o + d * h4.x;
+    f3 colour = F3(M.colour[0], M.colour[1], M.colour[2]);
+    const uint32_t nl = S.num_lights;
+    q4 out;
+    if (M.kind == RT_MAT_MATTE) {   // main.cpp:1143-1165
+        f3 L = (colour * M.ka) * ambient_L(S, B, p);
+        for (uint32_t l = 0; l < nl; ++l) {
+            f3 wi = light_direction(S.lights[l], P);
+            float nDotWi = dot(N, wi);
+            if (nDotWi > 0.0f) L = L + ((colour * M.kd) * 0.318309886183790671537767526745028724f) * light_L(S.lights[l]) * nDotWi;
+        }
+        out = {L.x, L.y, L.z, 0.0f};
+    } else if (M.kind == RT_MAT_SPECULAR) {   // main.cpp:1215-1244
+        f3 wo = normalize(-d);
+        f3 L = (colour * M.ka) * ambient_L(S, B, p);
+        for (uint32_t l = 0; l < nl; ++l) {
+            f3 wi = normalize(light_direction(S.lights[l], P));
+            float nDotWi = dot(N, wi);
+            if (nDotWi > 0.0f) {
+                float shadow = B.sh_res[p * nl + l];
+                L = L + ((colour * M.kd) * 0.318309886183790671537767526745028724f) * light_L(S.lights[l]) * nDotWi * shadow;
+                float sp = specular_fn(M.ks, M.spec_exp, N, wo, wi);
+                L = L + F3(sp, sp, sp) * shadow;
+            }
+        }
+        L = clamp01(L);
+        out = {L.x, L.y, L.z, 0.0f};
+    } else if (M.kind == RT_MAT_TEXTURED) {   // main.cpp:1269-1299
+        f3 tex = texture_colour(S, M.texture, h4.z, h4.w);
+        f3 wo = normalize(-d);
+        f3 L = (F3(1.0f, 1.0f, 1.0f) * M.ka) * ambient_L(S, B, p) * tex;
+        for (uint32_t l = 0; l < nl; ++l) {
+            f3 wi = normalize(light_direction(S.lights[l], P));
+            float nDotWi = dot(N, wi);
+            if (nDotWi > 0.0f) {
+                float shadow = B.sh_res[p * nl + l];
+                float ldist = length(light_source(S.lights[l], P) - P);
+                float att = A.light_atten / (ldist * ldist);
+                L = L + tex * light_L(S.lights[l]) * nDotWi * att * shadow;
+                float sp = specular_fn(M.ks, M.spec_exp, N, wo, wi);
+                L = L + F3(sp, sp, sp) * att * shadow;
+            }
+        }
+        L = clamp01(L);
+        out = {L.x, L.y, L.z, 0.0f};
+    } else {   // MIRROR (main.cpp:1487-1511): store the ambient term and the per-light phong terms
+        f3 wo = normalize(-d);
+        f3 L = (colour * M.ka) * ambient_L(S, B, p);
+        out = {L.x, L.y, L.z, 0.0f};
+        for (uint32_t l = 0; l < nl; ++l) {
+            f3 wi = normalize(light_direction(S.lights[l], P));
+            float sp = dot(N, wi) > 0.0f ? specular_fn(M.ks, M.spec_exp, N, wo, wi) : 0.0f;
+            if (l == 0) out.w = sp; else B.lvl_ph[li * (nl - 1) + (l - 1)] = sp;
+        }
+    }
+    B.lvl[li] = out;
+}
+
+// per pixel: unwind every sample's chain deepest level first, average, store
+RT_FN void resolve_item(const DScene& S, const RenderArgs& A, const Batch& B, uint32_t q)
+{
+    PathPix px = pix_of(A, q);
+    if (!px.valid) return;
+    const uint32_t nl = S.num_lights;
+    f3 sum = F3(0.0f, 0.0f, 0.0f);
+    for (int j = 0; j < A.spp; ++j) {
+        uint32_t p = (uint32_t)j * A.npx + q;
+        int top = 0;
+        while (top < A.levels) {
+            uint8_t k = B.lvl_kind[(size_t)top * B.P + p];
+            if (k == LK_MIRROR || k == LK_REFRACT) top++; else break;
+        }
+        f3 L = F3(0.0f, 0.0f, 0.0f);
+        bool hit0 = B.lvl_kind[p] != LK_NONE;
+        if (top < A.levels && B.lvl_kind[(size_t)top * B.P + p] == LK_TERMINAL) L = xyz(B.lvl[(size_t)top * B.P + p]);
+        for (int dlv = top - 1; dlv >= 0; --dlv) {
+            size_t li = (size_t)dlv * B.P + p;
+            if (B.lvl_kind[li] == LK_MIRROR) {
+                q4 m = B.lvl[li];
+                L = xyz(m) + L;                       // L = ambient; L += rho
+                if (nl > 0) L = L + F3(m.w, m.w, m.w);  // L += phong (light 0)
+                for (uint32_t l = 1; l < nl; ++l) { float sp = B.lvl_ph[li * (nl - 1) + (l - 1)]; L = L + F3(sp, sp, sp); }
+            }
+            L = clamp01(L);
+        }
+        if (hit0) sum = sum + L;
+    }
+    float avg = 1.0f / (float)A.spp;
+    float* o = A.out_rgb + px.out * 3;
+    o[0] = sum.x * avg; o[1] = sum.y * avg; o[2] = sum.z * avg;
+}
+
+// ---- host-side sequencing ---------------------------------------------------------------------------
+// Backend concept:
+//   void begin_batch(const RenderArgs&)          zero the per-batch counters
+//   void raygen(A, n) / trace(A,d,n,fixed) / prep / shadow / ao / shade / resolve(A, n)
+// where for depth > 0 the item count lives in device memory (counter index given) and the
+// backend launches a grid-stride kernel that reads it.
+template <class Backend>
+void render_frame(Backend& be, RenderArgs A, uint32_t owned_tiles, uint32_t tiles_per_batch, bool bounces)
+{
+    for (uint32_t first = 0; first < owned_tiles; first += tiles_per_batch) {
+        A.first_tile = first;
+        A.num_tiles = owned_tiles - first < tiles_per_batch ? owned_tiles - first : tiles_per_batch;
+        A.npx = A.num_tiles * RT_TILE * RT_TILE;
+        uint32_t paths = A.npx * (uint32_t)A.spp;
+        be.begin_batch(A);
+        be.raygen(A, paths);
+        int levels = bounces ? A.levels : 1;
+        for (int d = 0; d < levels; ++d) {
+            be.trace(A, d, paths);
+            be.prep(A, d, paths);
+            be.shadow(A, d);
+            be.ao(A, d);
+            be.shade(A, d, paths);
+        }
+        be.resolve(A, A.npx);
+    }
+}
+
+} // namespace rt

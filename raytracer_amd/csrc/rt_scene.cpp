@@ -1,0 +1,495 @@
+// rt_scene.cpp — validation, reference-structure rebuild and triangle-BVH construction.
+#include "rt_scene.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <numeric>
+
+namespace rt {
+
+namespace {
+
+inline void box_start(Aabb& b, const float* p) { for (int k = 0; k < 3; ++k) b.mn[k] = b.mx[k] = p[k]; }
+// BoundingVolumeBox::addVolumePoint (reference main.cpp:197-227): strict comparisons, min/max only
+inline void box_add(Aabb& b, const float* p)
+{
+    for (int k = 0; k < 3; ++k) {
+        if (p[k] < b.mn[k]) b.mn[k] = p[k];
+        if (p[k] > b.mx[k]) b.mx[k] = p[k];
+    }
+}
+inline void box_merge(Aabb& b, const Aabb& o) { box_add(b, o.mn); box_add(b, o.mx); }
+// BoundingVolumeBox::updateMinMaxCentroid (main.cpp:240-242)
+inline void centroid(const Aabb& b, float* c) { for (int k = 0; k < 3; ++k) c[k] = (b.mn[k] + b.mx[k]) / 2.0f; }
+
+} // namespace
+
+int HostScene::validate()
+{
+    auto bad = [&](const char* m) { error = m; return (int)RT_ERR_INVALID; };
+    const uint32_t nm = (uint32_t)materials.size();
+    for (auto& m : materials) {
+        if (m.kind < RT_MAT_MATTE || m.kind > RT_MAT_REFRACTION) return bad("material: unknown kind");
+        if (m.kind == RT_MAT_TEXTURED && m.texture >= (int32_t)textures.size()) return bad("material: texture index out of range");
+    }
+    auto mat_ok = [&](int32_t m) { return m >= 0 && (uint32_t)m < nm; };
+    for (auto& p : planes) {
+        if (!mat_ok(p.material)) return bad("plane: material index out of range");
+        if (materials[p.material].kind == RT_MAT_TEXTURED) { error = "Textured material on a Plane reads a stale uv in the reference (SURVEY Q16): unsupported"; return RT_ERR_UNSUPPORTED; }
+    }
+    for (auto& s : spheres) {
+        if (!mat_ok(s.material)) return bad("sphere: material index out of range");
+        if (materials[s.material].kind == RT_MAT_TEXTURED) { error = "Textured material on a Sphere reads a stale uv in the reference (SURVEY Q16): unsupported"; return RT_ERR_UNSUPPORTED; }
+    }
+    for (auto& t : triangles) if (!mat_ok(t.material)) return bad("triangle: material index out of range");
+    std::vector<uint8_t> tri_in_mesh(triangles.size(), 0);
+    for (auto& m : meshes) {
+        if (m.num_triangles == 0) return bad("mesh: empty");
+        if ((uint64_t)m.first_triangle + m.num_triangles > triangles.size()) return bad("mesh: triangle run out of range");
+        for (uint32_t k = 0; k < m.num_triangles; ++k) tri_in_mesh[m.first_triangle + k] = 1;
+    }
+    std::vector<uint8_t> mesh_in_mm(meshes.size(), 0);
+    for (auto& mm : multimeshes) {
+        if (mm.num_meshes == 0) return bad("multimesh: empty");
+        if ((uint64_t)mm.first_mesh + mm.num_meshes > meshes.size()) return bad("multimesh: mesh run out of range");
+        for (uint32_t k = 0; k < mm.num_meshes; ++k) mesh_in_mm[mm.first_mesh + k] = 1;
+    }
+    auto ref_ok = [&](const rt_shape_ref& r, bool in_bvh) -> int {
+        switch (r.kind) {
+        case RT_SHAPE_PLANE: if (in_bvh) { error = "Plane has no getBoundingBoxPoints(): cannot be a BVHAccel leaf"; return RT_ERR_INVALID; }
+            return r.index < planes.size() ? RT_OK : bad("shape ref: plane index");
+        case RT_SHAPE_SPHERE: return r.index < spheres.size() ? RT_OK : bad("shape ref: sphere index");
+        case RT_SHAPE_TRIANGLE:
+            if (r.index >= triangles.size()) return bad("shape ref: triangle index");
+            if (tri_in_mesh[r.index]) return bad("shape ref: triangle belongs to a mesh");
+            return RT_OK;
+        case RT_SHAPE_MESH:
+            if (r.index >= meshes.size()) return bad("shape ref: mesh index");
+            if (mesh_in_mm[r.index]) return bad("shape ref: mesh belongs to a multimesh");
+            return RT_OK;
+        case RT_SHAPE_MULTIMESH: return r.index < multimeshes.size() ? RT_OK : bad("shape ref: multimesh index");
+        case RT_SHAPE_BVH:
+            if (in_bvh) { error = "nested BVHAccel is not supported"; return RT_ERR_UNSUPPORTED; }
+            return r.index < bvhs.size() ? RT_OK : bad("shape ref: bvh index");
+        }
+        return bad("shape ref: unknown kind");
+    };
+    for (auto& b : bvhs) {
+        if (b.num_leaves == 0) return bad("bvh: no leaves (the reference indexes mHeirarchy[size-1])");
+        if ((uint64_t)b.first_leaf + b.num_leaves > bvh_leaves.size()) return bad("bvh: leaf run out of range");
+        for (uint32_t k = 0; k < b.num_leaves; ++k) { int rc = ref_ok(bvh_leaves[b.first_leaf + k], true); if (rc) return rc; }
+    }
+    for (auto& r : scene) { int rc = ref_ok(r, false); if (rc) return rc; }
+    for (auto& l : lights) if (l.kind != RT_LIGHT_POINT && l.kind != RT_LIGHT_DIRECTIONAL) return bad("light: unknown kind");
+    if (ambient.occlusion_samples < 0 || ambient.occlusion_samples > 64) return bad("ambient: occlusion_samples out of range [0,64]");
+    if (triangles.size() >= (1u << 28)) { error = "more than 2^28 triangles"; return RT_ERR_UNSUPPORTED; }
+    return RT_OK;
+}
+
+int HostScene::shape_box(const rt_shape_ref& r, Aabb& out)
+{
+    switch (r.kind) {
+    case RT_SHAPE_SPHERE: {   // Sphere::getBoundingBoxPoints (main.cpp:571-576)
+        const rt_sphere& s = spheres[r.index];
+        float hi[3], lo[3];
+        for (int k = 0; k < 3; ++k) { hi[k] = s.centre[k] + s.radius; lo[k] = s.centre[k] - s.radius; }
+        box_start(out, hi); box_add(out, lo);
+        return RT_OK;
+    }
+    case RT_SHAPE_TRIANGLE: { // Triangle::getBoundingBoxPoints (main.cpp:705-711)
+        const rt_triangle& t = triangles[r.index];
+        box_start(out, t.v0); box_add(out, t.v1); box_add(out, t.v2);
+        return RT_OK;
+    }
+    case RT_SHAPE_MESH: out = mesh_box_[r.index]; return RT_OK;
+    case RT_SHAPE_MULTIMESH: out = mm_box_[r.index]; return RT_OK;
+    }
+    error = "shape has no bounding box";
+    return RT_ERR_INVALID;
+}
+
+uint32_t HostScene::prim_count(const rt_shape_ref& r)
+{
+    switch (r.kind) {
+    case RT_SHAPE_MESH: return meshes[r.index].num_triangles;
+    case RT_SHAPE_MULTIMESH: {
+        uint32_t n = 0;
+        for (uint32_t k = 0; k < multimeshes[r.index].num_meshes; ++k) n += meshes[multimeshes[r.index].first_mesh + k].num_triangles;
+        return n;
+    }
+    case RT_SHAPE_BVH: {
+        uint32_t n = 0;
+        for (uint32_t k = 0; k < bvhs[r.index].num_leaves; ++k) n += prim_count(bvh_leaves[bvhs[r.index].first_leaf + k]);
+        return n;
+    }
+    default: return 1;
+    }
+}
+
+// BVHAccel::addShape + generateBVH (main.cpp:323-423): layer by layer, repeatedly join the two
+// not-yet-joined nodes of the layer whose box centres are closest (scanning from the highest
+// index down, first strict minimum wins); a left-over node is copied up unchanged.
+int HostScene::reference_hierarchy(const rt_bvh& b, std::vector<RefNode>& H)
+{
+    H.clear();
+    for (uint32_t k = 0; k < b.num_leaves; ++k) {
+        RefNode n{};
+        n.leaf = true; n.shape = bvh_leaves[b.first_leaf + k]; n.accessed = false;
+        int rc = shape_box(n.shape, n.box);
+        if (rc) return rc;
+        H.push_back(n);
+    }
+    size_t layer = H.size();
+    while (layer != 1) {
+        const size_t next_layer = (size_t)std::ceil((float)layer / 2.0f);
+        const int end = (int)H.size(), begin = (int)(H.size() - layer);
+        for (size_t made = 0; made < next_layer; ++made) {
+            int bi = -1, bk = -1;
+            float best = std::numeric_limits<float>::max();
+            for (int i = end - 1; i > begin; --i) {
+                if (H[i].accessed) continue;
+                float ci[3]; centroid(H[i].box, ci);
+                for (int k = i - 1; k >= begin; --k) {
+                    if (H[k].accessed) continue;
+                    float ck[3]; centroid(H[k].box, ck);
+                    float dx = ck[0] - ci[0], dy = ck[1] - ci[1], dz = ck[2] - ci[2];
+                    float dist = sqrtf(dx * dx + dy * dy + dz * dz);   // glm::distance = length(p1 - p0)
+                    if (dist < best) { best = dist; bi = i; bk = k; }
+                }
+            }
+            if (bi < 0) {
+                for (int i = end - 1; i >= begin; --i)
+                    if (!H[i].accessed) { RefNode c = H[i]; H.push_back(c); H[i].accessed = true; break; }
+            } else {
+                RefNode n{};
+                n.leaf = false; n.left = (uint32_t)bi; n.right = (uint32_t)bk; n.accessed = false;
+                n.box = H[bi].box; box_merge(n.box, H[bk].box);
+                H.push_back(n);
+                H[bi].accessed = true; H[bk].accessed = true;
+            }
+        }
+        layer = next_layer;
+    }
+    return RT_OK;
+}
+
+uint32_t HostScene::add_triangle_slot(uint32_t gid, uint32_t rank_off)
+{
+    const rt_triangle& t = triangles[gid];
+    uint32_t slot = (uint32_t)(tris4.size() / 3);
+    q4 a = {t.v0[0], t.v0[1], t.v0[2], u2f(gid)};
+    q4 b = {t.v1[0] - t.v0[0], t.v1[1] - t.v0[1], t.v1[2] - t.v0[2], u2f((uint32_t)t.material)};
+    q4 c = {t.v2[0] - t.v0[0], t.v2[1] - t.v0[1], t.v2[2] - t.v0[2], u2f(rank_off)};
+    tris4.push_back(a); tris4.push_back(b); tris4.push_back(c);
+    return slot;
+}
+
+// ---- triangle BVH of one Mesh: binned SAH, <= 4 triangles per leaf, 64-byte two-child nodes ----
+namespace {
+struct BuildTri { float mn[3], mx[3], c[3]; uint32_t gid; };
+constexpr uint32_t kLeafMax = 4;
+constexpr int kMaxDepth = 30;   // inner-node depth bound; the kernels keep RT_STACK_DEPTH = 32 entries
+constexpr int kBins = 16;
+
+inline float half_area(const float* mn, const float* mx)
+{
+    float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+} // namespace
+
+uint32_t HostScene::mesh_bvh(uint32_t mesh)
+{
+    if (mesh_root_[mesh] != 0xFFFFFFFFu) return mesh_root_[mesh];
+    const rt_mesh& m = meshes[mesh];
+    std::vector<BuildTri> T(m.num_triangles);
+    for (uint32_t k = 0; k < m.num_triangles; ++k) {
+        const rt_triangle& t = triangles[m.first_triangle + k];
+        BuildTri& b = T[k];
+        b.gid = m.first_triangle + k;
+        for (int a = 0; a < 3; ++a) {
+            b.mn[a] = std::min(t.v0[a], std::min(t.v1[a], t.v2[a]));
+            b.mx[a] = std::max(t.v0[a], std::max(t.v1[a], t.v2[a]));
+            b.c[a] = 0.5f * (b.mn[a] + b.mx[a]);
+        }
+    }
+    auto bounds = [&](uint32_t lo, uint32_t hi, float* mn, float* mx) {
+        for (int a = 0; a < 3; ++a) { mn[a] = INFINITY; mx[a] = -INFINITY; }
+        for (uint32_t i = lo; i < hi; ++i)
+            for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], T[i].mn[a]); mx[a] = std::max(mx[a], T[i].mx[a]); }
+    };
+    auto make_leaf = [&](uint32_t lo, uint32_t hi) -> uint32_t {
+        uint32_t first = 0;
+        for (uint32_t i = lo; i < hi; ++i) {
+            uint32_t s = add_triangle_slot(T[i].gid, T[i].gid - m.first_triangle);
+            if (i == lo) first = s;
+        }
+        return REF_LEAF | ((hi - lo - 1u) << 28) | first;
+    };
+    uint32_t max_depth_seen = 0;
+    // returns the child reference for T[lo,hi); inner nodes are appended to nodes4
+    std::function<uint32_t(uint32_t, uint32_t, int)> build = [&](uint32_t lo, uint32_t hi, int depth) -> uint32_t {
+        const uint32_t n = hi - lo;
+        if (n <= kLeafMax) return make_leaf(lo, hi);
+        max_depth_seen = std::max<uint32_t>(max_depth_seen, (uint32_t)depth + 1);
+        // centroid bounds
+        float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = lo; i < hi; ++i)
+            for (int a = 0; a < 3; ++a) { cmn[a] = std::min(cmn[a], T[i].c[a]); cmx[a] = std::max(cmx[a], T[i].c[a]); }
+        int best_axis = -1, best_bin = -1;
+        float best_cost = INFINITY;
+        for (int a = 0; a < 3; ++a) {
+            float ext = cmx[a] - cmn[a];
+            if (!(ext > 0.0f)) continue;
+            uint32_t cnt[kBins] = {0};
+            float bmn[kBins][3], bmx[kBins][3];
+            for (int b = 0; b < kBins; ++b) for (int k = 0; k < 3; ++k) { bmn[b][k] = INFINITY; bmx[b][k] = -INFINITY; }
+            float scale = (float)kBins / ext;
+            for (uint32_t i = lo; i < hi; ++i) {
+                int b = std::min(kBins - 1, std::max(0, (int)((T[i].c[a] - cmn[a]) * scale)));
+                cnt[b]++;
+                for (int k = 0; k < 3; ++k) { bmn[b][k] = std::min(bmn[b][k], T[i].mn[k]); bmx[b][k] = std::max(bmx[b][k], T[i].mx[k]); }
+            }
+            float rarea[kBins]; uint32_t rcnt[kBins];
+            float amn[3] = {INFINITY, INFINITY, INFINITY}, amx[3] = {-INFINITY, -INFINITY, -INFINITY};
+            uint32_t c = 0;
+            for (int b = kBins - 1; b > 0; --b) {
+                c += cnt[b];
+                for (int k = 0; k < 3; ++k) { amn[k] = std::min(amn[k], bmn[b][k]); amx[k] = std::max(amx[k], bmx[b][k]); }
+                rcnt[b] = c; rarea[b] = c ? half_area(amn, amx) : 0.0f;
+            }
+            for (int k = 0; k < 3; ++k) { amn[k] = INFINITY; amx[k] = -INFINITY; }
+            c = 0;
+            for (int b = 0; b < kBins - 1; ++b) {
+                c += cnt[b];
+                for (int k = 0; k < 3; ++k) { amn[k] = std::min(amn[k], bmn[b][k]); amx[k] = std::max(amx[k], bmx[b][k]); }
+                if (c == 0 || rcnt[b + 1] == 0) continue;
+                float cost = half_area(amn, amx) * (float)c + rarea[b + 1] * (float)rcnt[b + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+            }
+        }
+        uint32_t mid = lo;
+        const uint64_t cap_child = (uint64_t)kLeafMax << std::max(0, kMaxDepth - depth - 1);
+        if (best_axis >= 0) {
+            float ext = cmx[best_axis] - cmn[best_axis];
+            float scale = (float)kBins / ext;
+            auto it = std::partition(T.begin() + lo, T.begin() + hi, [&](const BuildTri& t) {
+                int b = std::min(kBins - 1, std::max(0, (int)((t.c[best_axis] - cmn[best_axis]) * scale)));
+                return b <= best_bin;
+            });
+            mid = (uint32_t)(it - T.begin());
+        }
+        if (mid == lo || mid == hi || (uint64_t)(mid - lo) > cap_child || (uint64_t)(hi - mid) > cap_child) {
+            // median split along the widest centroid axis (also the depth-bounding fallback)
+            int a = 0;
+            if (cmx[1] - cmn[1] > cmx[a] - cmn[a]) a = 1;
+            if (cmx[2] - cmn[2] > cmx[a] - cmn[a]) a = 2;
+            mid = lo + n / 2;
+            std::nth_element(T.begin() + lo, T.begin() + mid, T.begin() + hi,
+                             [&](const BuildTri& x, const BuildTri& y) { return x.c[a] < y.c[a]; });
+        }
+        const size_t me = nodes4.size() / 4;
+        nodes4.resize(nodes4.size() + 4);
+        float lmn[3], lmx[3], rmn[3], rmx[3];
+        bounds(lo, mid, lmn, lmx); bounds(mid, hi, rmn, rmx);
+        uint32_t l = build(lo, mid, depth + 1);
+        uint32_t r = build(mid, hi, depth + 1);
+        nodes4[me * 4 + 0] = {lmn[0], lmn[1], lmn[2], lmx[0]};
+        nodes4[me * 4 + 1] = {lmx[1], lmx[2], rmn[0], rmn[1]};
+        nodes4[me * 4 + 2] = {rmn[2], rmx[0], rmx[1], rmx[2]};
+        nodes4[me * 4 + 3] = {u2f(l), u2f(r), 0.0f, 0.0f};
+        return (uint32_t)me;
+    };
+    uint32_t root;
+    if (m.num_triangles <= kLeafMax) {
+        float mn[3], mx[3];
+        bounds(0, m.num_triangles, mn, mx);
+        root = (uint32_t)(nodes4.size() / 4);
+        uint32_t leaf = make_leaf(0, m.num_triangles);
+        nodes4.push_back({mn[0], mn[1], mn[2], mx[0]});
+        nodes4.push_back({mx[1], mx[2], INFINITY, INFINITY});
+        nodes4.push_back({INFINITY, -INFINITY, -INFINITY, -INFINITY});
+        nodes4.push_back({u2f(leaf), u2f((uint32_t)REF_NONE), 0.0f, 0.0f});
+    } else {
+        root = build(0, m.num_triangles, 0);
+    }
+    bvh_max_depth = std::max(bvh_max_depth, max_depth_seen);
+    mesh_root_[mesh] = root;
+    return root;
+}
+
+void HostScene::emit_mesh(uint32_t mesh, uint32_t item, uint32_t rank_base)
+{
+    GateNode g{};
+    std::memcpy(g.mn, mesh_box_[mesh].mn, 12); std::memcpy(g.mx, mesh_box_[mesh].mx, 12);
+    g.kind = G_MESH; g.a = mesh_bvh(mesh); g.rank = rank_base; g.prim = meshes[mesh].first_triangle; g.item = item;
+    g.skip = (uint32_t)gates.size() + 1;
+    gates.push_back(g);
+}
+
+int HostScene::emit_bvh(uint32_t bvh, uint32_t item, uint32_t rank_base)
+{
+    std::vector<RefNode> H;
+    int rc = reference_hierarchy(bvhs[bvh], H);
+    if (rc) return rc;
+    const uint32_t root = (uint32_t)H.size() - 1;
+    // ranks follow the reference's breadth-first visiting order (BVHAccel::hit, main.cpp:425-470)
+    std::vector<uint32_t> rank(H.size(), 0);
+    {
+        std::vector<uint32_t> q{root};
+        uint32_t r = rank_base;
+        for (size_t h = 0; h < q.size(); ++h) {
+            const RefNode& n = H[q[h]];
+            if (n.leaf) { rank[q[h]] = r; r += prim_count(n.shape); }
+            else { q.push_back(n.left); q.push_back(n.right); }
+        }
+    }
+    std::function<void(uint32_t)> emit = [&](uint32_t i) {
+        const RefNode& n = H[i];
+        if (n.leaf) { emit_shape(n.shape, item, rank[i]); return; }
+        size_t me = gates.size();
+        GateNode g{};
+        std::memcpy(g.mn, n.box.mn, 12); std::memcpy(g.mx, n.box.mx, 12);
+        g.kind = G_GATED; g.item = item;
+        gates.push_back(g);
+        emit(n.left); emit(n.right);
+        gates[me].skip = (uint32_t)gates.size();
+    };
+    emit(root);
+    return RT_OK;
+}
+
+void HostScene::emit_shape(const rt_shape_ref& r, uint32_t item, uint32_t rank_base)
+{
+    GateNode g{};
+    g.item = item; g.rank = rank_base;
+    switch (r.kind) {
+    case RT_SHAPE_PLANE: g.kind = G_PLANE; g.a = r.index; g.skip = (uint32_t)gates.size() + 1; gates.push_back(g); break;
+    case RT_SHAPE_SPHERE: g.kind = G_SPHERE; g.a = r.index; g.skip = (uint32_t)gates.size() + 1; gates.push_back(g); break;
+    case RT_SHAPE_TRIANGLE: g.kind = G_TRI; g.a = add_triangle_slot(r.index, 0); g.skip = (uint32_t)gates.size() + 1; gates.push_back(g); break;
+    case RT_SHAPE_MESH: emit_mesh(r.index, item, rank_base); break;
+    case RT_SHAPE_MULTIMESH: {
+        size_t me = gates.size();
+        std::memcpy(g.mn, mm_box_[r.index].mn, 12); std::memcpy(g.mx, mm_box_[r.index].mx, 12);
+        g.kind = G_GATED;
+        gates.push_back(g);
+        uint32_t rank = rank_base;
+        for (uint32_t k = 0; k < multimeshes[r.index].num_meshes; ++k) {
+            uint32_t mi = multimeshes[r.index].first_mesh + k;
+            emit_mesh(mi, item, rank);
+            rank += meshes[mi].num_triangles;
+        }
+        gates[me].skip = (uint32_t)gates.size();
+        break;
+    }
+    case RT_SHAPE_BVH: emit_bvh(r.index, item, rank_base); break;
+    }
+}
+
+bool HostScene::subtree_opaque(const rt_shape_ref& r)
+{
+    auto opaque = [&](int32_t m) { return materials[m].kind != RT_MAT_REFRACTION; };
+    switch (r.kind) {
+    case RT_SHAPE_PLANE: return opaque(planes[r.index].material);
+    case RT_SHAPE_SPHERE: return opaque(spheres[r.index].material);
+    case RT_SHAPE_TRIANGLE: return opaque(triangles[r.index].material);
+    case RT_SHAPE_MESH:
+        for (uint32_t k = 0; k < meshes[r.index].num_triangles; ++k) if (!opaque(triangles[meshes[r.index].first_triangle + k].material)) return false;
+        return true;
+    case RT_SHAPE_MULTIMESH:
+        for (uint32_t k = 0; k < multimeshes[r.index].num_meshes; ++k) if (!subtree_opaque({RT_SHAPE_MESH, multimeshes[r.index].first_mesh + k})) return false;
+        return true;
+    case RT_SHAPE_BVH:
+        for (uint32_t k = 0; k < bvhs[r.index].num_leaves; ++k) if (!subtree_opaque(bvh_leaves[bvhs[r.index].first_leaf + k])) return false;
+        return true;
+    }
+    return false;
+}
+
+int HostScene::build()
+{
+    error.clear();
+    int rc = validate();
+    if (rc) return rc;
+    gates.clear(); planes4.clear(); spheres4.clear(); tris4.clear(); attr4.clear(); nodes4.clear();
+    dmaterials.clear(); dlights.clear(); dtextures.clear(); texels.clear(); item_opaque.clear();
+    bvh_max_depth = 0;
+
+    // Mesh / MultiMesh gate boxes (main.cpp:875-881, 757-765)
+    mesh_box_.assign(meshes.size(), Aabb{});
+    for (size_t i = 0; i < meshes.size(); ++i) {
+        Aabb& b = mesh_box_[i];
+        box_start(b, triangles[meshes[i].first_triangle].v0);
+        for (uint32_t k = 0; k < meshes[i].num_triangles; ++k) {
+            const rt_triangle& t = triangles[meshes[i].first_triangle + k];
+            box_add(b, t.v0); box_add(b, t.v1); box_add(b, t.v2);
+        }
+    }
+    mm_box_.assign(multimeshes.size(), Aabb{});
+    for (size_t i = 0; i < multimeshes.size(); ++i) {
+        mm_box_[i] = mesh_box_[multimeshes[i].first_mesh];
+        for (uint32_t k = 0; k < multimeshes[i].num_meshes; ++k) box_merge(mm_box_[i], mesh_box_[multimeshes[i].first_mesh + k]);
+    }
+    mesh_root_.assign(meshes.size(), 0xFFFFFFFFu);
+
+    for (auto& p : planes) {
+        planes4.push_back({p.point[0], p.point[1], p.point[2], u2f((uint32_t)p.material)});
+        planes4.push_back({p.normal[0], p.normal[1], p.normal[2], 0.0f});
+    }
+    for (auto& s : spheres) {
+        spheres4.push_back({s.centre[0], s.centre[1], s.centre[2], s.radius});
+        spheres4.push_back({s.radius * s.radius, u2f((uint32_t)s.material), 0.0f, 0.0f});   // mRadiusSqr{radius*radius}
+    }
+    extent = 1.0f;
+    for (auto& t : triangles) {
+        attr4.push_back({t.uv0[0], t.uv0[1], t.uv1[0], t.uv1[1]});
+        attr4.push_back({t.uv2[0], t.uv2[1], 0.0f, 0.0f});
+        for (int k = 0; k < 3; ++k) extent = std::max(extent, std::max(std::fabs(t.v0[k]), std::max(std::fabs(t.v1[k]), std::fabs(t.v2[k]))));
+    }
+
+    // gate nodes in scene order; ranks = the reference's visiting order
+    uint32_t rank = 0;
+    for (uint32_t i = 0; i < scene.size(); ++i) {
+        if (scene[i].kind == RT_SHAPE_BVH) {
+            const rt_bvh& b = bvhs[scene[i].index];
+            if (b.num_leaves == 1) emit_shape(bvh_leaves[b.first_leaf], i, rank);   // root.leaf: shape->hit, no gate
+            else { rc = emit_bvh(scene[i].index, i, rank); if (rc) return rc; }
+        } else {
+            emit_shape(scene[i], i, rank);
+        }
+        rank += prim_count(scene[i]);
+        item_opaque.push_back(subtree_opaque(scene[i]) ? 1 : 0);
+    }
+    if (item_opaque.empty()) item_opaque.push_back(1);
+    if (bvh_max_depth > (uint32_t)kMaxDepth + 1) { error = "triangle BVH deeper than the traversal stack"; return RT_ERR_UNSUPPORTED; }
+
+    has_bounce_materials = false;
+    for (auto& m : materials) {
+        DMaterial d{};
+        d.kind = m.kind; std::memcpy(d.colour, m.colour, 12);
+        d.kd = m.kd; d.ka = m.ka; d.ks = m.ks; d.spec_exp = m.spec_exp; d.ior = m.ior; d.texture = m.texture;
+        dmaterials.push_back(d);
+        if (m.kind == RT_MAT_MIRROR || m.kind == RT_MAT_REFRACTION) has_bounce_materials = true;
+    }
+    for (auto& l : lights) {
+        DLight d{};
+        d.kind = l.kind; std::memcpy(d.colour, l.colour, 12); d.radiance = l.radiance;
+        if (l.kind == RT_LIGHT_DIRECTIONAL) {   // Directional::setDirection normalises (main.cpp:1315-1318)
+            f3 n = normalize(F3(l.v[0], l.v[1], l.v[2]));
+            d.v[0] = n.x; d.v[1] = n.y; d.v[2] = n.z;
+        } else std::memcpy(d.v, l.v, 12);
+        dlights.push_back(d);
+    }
+    for (auto& t : textures) {
+        DTexture d{};
+        d.offset = (uint32_t)texels.size(); d.width = t.width; d.height = t.height;
+        d.set = (t.rgba && t.width > 0 && t.height > 0) ? 1 : 0;
+        if (d.set) texels.insert(texels.end(), t.rgba, t.rgba + (size_t)t.width * t.height * 4);
+        dtextures.push_back(d);
+    }
+    return RT_OK;
+}
+
+} // namespace rt

@@ -1,0 +1,67 @@
+// rt_scene.hpp — host-side scene store and flattener (no HIP here: pure C++17).
+//
+// Holds the copies made by rt_scene_set_*, validates them, rebuilds the reference's
+// shape-level structure (BoundingVolumeBox / Mesh / MultiMesh gates and BVHAccel's bottom-up
+// nearest-centroid hierarchy, reference main.cpp:191-243, 323-423, 742-766, 851-882) and
+// builds one binned-SAH triangle BVH per Mesh in the 64-byte node layout the kernels fetch.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "rt_core.hpp"
+
+namespace rt {
+
+struct Aabb { float mn[3], mx[3]; };
+
+struct HostScene {
+    // ---- description (copied from the caller) ----
+    std::vector<rt_plane> planes;
+    std::vector<rt_sphere> spheres;
+    std::vector<rt_triangle> triangles;
+    std::vector<rt_mesh> meshes;
+    std::vector<rt_multimesh> multimeshes;
+    std::vector<rt_bvh> bvhs;
+    std::vector<rt_shape_ref> bvh_leaves;
+    std::vector<rt_shape_ref> scene;
+    std::vector<rt_material> materials;
+    std::vector<rt_texture> textures;              // rgba pointers re-targeted into texel_store
+    std::vector<std::vector<uint8_t>> texel_store;
+    std::vector<rt_light> lights;
+    rt_ambient ambient{};
+
+    // ---- flattened form (what gets uploaded) ----
+    std::vector<GateNode> gates;
+    std::vector<q4> planes4, spheres4, tris4, attr4, nodes4;
+    std::vector<DMaterial> dmaterials;
+    std::vector<DLight> dlights;
+    std::vector<DTexture> dtextures;
+    std::vector<uint8_t> texels;
+    std::vector<uint8_t> item_opaque;
+    float extent = 0.0f;
+    bool has_bounce_materials = false;
+    uint32_t bvh_max_depth = 0;
+
+    std::string error;
+
+    int build();   // rt_status
+
+    // reference hierarchy of one BVHAccel, exposed for tests (node = {leaf,left,right,box})
+    struct RefNode { bool leaf; rt_shape_ref shape; Aabb box; uint32_t left, right; bool accessed; };
+    int reference_hierarchy(const rt_bvh& b, std::vector<RefNode>& out);
+
+private:
+    std::vector<Aabb> mesh_box_, mm_box_;
+    std::vector<uint32_t> mesh_root_;          // triangle-BVH root per mesh (0xFFFFFFFF = not built yet)
+    int validate();
+    int shape_box(const rt_shape_ref& r, Aabb& out);
+    uint32_t prim_count(const rt_shape_ref& r);
+    uint32_t mesh_bvh(uint32_t mesh);
+    void emit_shape(const rt_shape_ref& r, uint32_t item, uint32_t rank_base);
+    void emit_mesh(uint32_t mesh, uint32_t item, uint32_t rank_base);
+    int emit_bvh(uint32_t bvh, uint32_t item, uint32_t rank_base);
+    uint32_t add_triangle_slot(uint32_t gid, uint32_t rank_off);
+    bool subtree_opaque(const rt_shape_ref& r);
+};
+
+} // namespace rt

@@ -1,0 +1,151 @@
+// tests/emul/emul.cpp — TEST-ONLY host emulation of the device pipeline.
+//
+// Compiles the very same per-item kernel bodies (raytracer_amd/csrc/rt_core.hpp,
+// rt_pipeline.hpp) and the host flattener (rt_scene.cpp) with g++ and runs them sequentially,
+// so the CPU test-suite (-m "not gpu") can check the device arithmetic, the flattened scene and
+// the triangle BVH against the oracle without a GPU.  It is not part of librt_amd.so and the
+// product never loads it.
+#include <cstring>
+#include <vector>
+
+#include "../../raytracer_amd/csrc/rt_pipeline.hpp"
+#include "../../raytracer_amd/csrc/rt_scene.hpp"
+
+using namespace rt;
+
+namespace {
+struct LoopBackend {
+    DScene S; Batch B; bool stats;
+    std::vector<uint32_t> stack = std::vector<uint32_t>(RT_STACK_DEPTH);
+    Counters cnt[3] = {};
+    void begin_batch(const RenderArgs&) { std::memset(B.counters, 0, sizeof(uint32_t) * C_TOTAL); }
+    void raygen(const RenderArgs& A, uint32_t n) { for (uint32_t i = 0; i < n; ++i) raygen_item(S, A, B, i); }
+    uint32_t count(int d, uint32_t fixed) { return d == 0 ? fixed : B.counters[C_QUEUE + d]; }
+    void trace(const RenderArgs& A, int d, uint32_t fixed) {
+        Stack st{stack.data(), 1};
+        for (uint32_t i = 0, n = count(d, fixed); i < n; ++i) trace_item<true>(S, A, B, d, i, st, cnt[0]);
+    }
+    void prep(const RenderArgs& A, int d, uint32_t fixed) { for (uint32_t i = 0, n = count(d, fixed); i < n; ++i) prep_item(S, A, B, d, i); }
+    void shadow(const RenderArgs& A, int d) {
+        Stack st{stack.data(), 1};
+        for (uint32_t i = 0, n = B.counters[C_SH + d]; i < n; ++i) shadow_item<true>(S, A, B, d, i, st, cnt[1]);
+    }
+    void ao(const RenderArgs& A, int d) {
+        Stack st{stack.data(), 1};
+        uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
+        for (uint32_t i = 0, n = B.counters[C_AO + d] * n2; i < n; ++i) ao_item<true>(S, A, B, d, i, st, cnt[2]);
+    }
+    void shade(const RenderArgs& A, int d, uint32_t fixed) { for (uint32_t i = 0, n = count(d, fixed); i < n; ++i) shade_item(S, A, B, d, i); }
+    void resolve(const RenderArgs& A, uint32_t n) {
+        for (uint32_t i = 0; i < n; ++i) resolve_item(S, A, B, i);
+        for (int d = 0; d < A.levels; ++d) {
+            B.stats[ST_SHADOW] += B.counters[C_SH + d];
+            B.stats[ST_AO] += (unsigned long long)B.counters[C_AO + d] * (unsigned)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
+            if (d > 0) B.stats[ST_BOUNCE] += B.counters[C_QUEUE + d];
+        }
+    }
+};
+} // namespace
+
+extern "C" {
+
+static std::string g_err;
+const char* emul_last_error() { return g_err.c_str(); }
+
+// out_counts: {primary, shadow, ao, bounce, nodes[3], tris[3], gates[3]}
+int emul_render(const rt_scene_desc* d, const rt_camera* cam, const rt_params* p,
+                float* rgb, uint32_t* primid, float* t, unsigned long long* out_counts)
+{
+    HostScene H;
+    H.planes.assign(d->planes, d->planes + d->num_planes);
+    H.spheres.assign(d->spheres, d->spheres + d->num_spheres);
+    H.triangles.assign(d->triangles, d->triangles + d->num_triangles);
+    H.meshes.assign(d->meshes, d->meshes + d->num_meshes);
+    H.multimeshes.assign(d->multimeshes, d->multimeshes + d->num_multimeshes);
+    H.bvhs.assign(d->bvhs, d->bvhs + d->num_bvhs);
+    H.bvh_leaves.assign(d->bvh_leaves, d->bvh_leaves + d->num_bvh_leaves);
+    H.scene.assign(d->scene, d->scene + d->num_scene);
+    H.materials.assign(d->materials, d->materials + d->num_materials);
+    H.textures.assign(d->textures, d->textures + d->num_textures);
+    H.lights.assign(d->lights, d->lights + d->num_lights);
+    H.ambient = d->ambient;
+    int rc = H.build();
+    if (rc) { g_err = H.error; return rc; }
+
+    LoopBackend be;
+    DScene& S = be.S;
+    S.gates = H.gates.data(); S.num_gates = (uint32_t)H.gates.size();
+    S.planes = H.planes4.data(); S.spheres = H.spheres4.data(); S.tris = H.tris4.data();
+    S.tri_attr = H.attr4.data(); S.nodes = H.nodes4.data();
+    S.materials = H.dmaterials.data(); S.lights = H.dlights.data(); S.num_lights = (uint32_t)H.dlights.size();
+    S.textures = H.dtextures.data(); S.texels = H.texels.data(); S.num_textures = (uint32_t)H.dtextures.size();
+    S.item_opaque = H.item_opaque.data(); S.num_items = (uint32_t)H.item_opaque.size();
+    S.ambient = H.ambient;
+    S.prim_base_sphere = (uint32_t)H.planes.size(); S.prim_base_tri = (uint32_t)(H.planes.size() + H.spheres.size());
+    S.cull_pad = 1.0f / 262144.0f; S.extent = H.extent;
+
+    RenderArgs A{};
+    A.cam = make_camera(*cam);
+    A.width = p->width; A.height = p->height; A.x0 = p->x0; A.y0 = p->y0; A.x1 = p->x1; A.y1 = p->y1;
+    A.spp = p->num_samples; A.sampler = p->sampler; A.max_depth = p->max_depth; A.levels = p->max_depth + 2;
+    A.light_atten = p->light_attenuation; A.seed = p->seed;
+    A.tiles_x = (uint32_t)((p->x1 - p->x0 + RT_TILE - 1) / RT_TILE); A.tiles_y = (uint32_t)((p->y1 - p->y0 + RT_TILE - 1) / RT_TILE);
+    A.tile_rank = p->tile_rank; A.tile_world = p->tile_world > 0 ? p->tile_world : 1;
+    A.out_rgb = rgb; A.out_prim = primid; A.out_t = t; A.slab = 0;
+    uint32_t total = A.tiles_x * A.tiles_y;
+    uint32_t owned = total > (uint32_t)A.tile_rank ? (total - A.tile_rank + A.tile_world - 1) / A.tile_world : 0;
+    uint32_t tiles_per_batch = 4;
+    uint32_t P = tiles_per_batch * RT_TILE * RT_TILE * (uint32_t)A.spp;
+    uint32_t nl = S.num_lights ? S.num_lights : 1;
+    uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
+    Batch& B = be.B;
+    B.P = P;
+    std::vector<q4> ro0(P), ro1(P), rd0(P), rd1(P), hit(P), nrm(P), lvl((size_t)P * A.levels);
+    std::vector<uint32_t> pstate(P), q0(P), q1(P), aoq(P), aos(P), shq((size_t)P * nl), counters(C_TOTAL);
+    std::vector<float> aot((size_t)P * (n2 ? n2 : 1)), shr((size_t)P * nl), lph((size_t)P * A.levels * (nl > 1 ? nl - 1 : 1));
+    std::vector<uint8_t> kind((size_t)P * A.levels);
+    std::vector<unsigned long long> stats(ST_TOTAL, 0);
+    B.ray_o[0] = ro0.data(); B.ray_o[1] = ro1.data(); B.ray_d[0] = rd0.data(); B.ray_d[1] = rd1.data();
+    B.hit = hit.data(); B.nrm = nrm.data(); B.pstate = pstate.data(); B.queue[0] = q0.data(); B.queue[1] = q1.data();
+    B.ao_queue = aoq.data(); B.ao_slot = aos.data(); B.sh_queue = shq.data(); B.ao_t = aot.data(); B.sh_res = shr.data();
+    B.lvl = lvl.data(); B.lvl_ph = lph.data(); B.lvl_kind = kind.data(); B.counters = counters.data(); B.stats = stats.data();
+    render_frame(be, A, owned, tiles_per_batch, H.has_bounce_materials);
+    if (out_counts) {
+        out_counts[0] = (unsigned long long)(p->x1 - p->x0) * (p->y1 - p->y0) * A.spp;
+        out_counts[1] = stats[ST_SHADOW]; out_counts[2] = stats[ST_AO]; out_counts[3] = stats[ST_BOUNCE];
+        for (int k = 0; k < 3; ++k) { out_counts[4 + k] = be.cnt[k].nodes; out_counts[7 + k] = be.cnt[k].tris; out_counts[10 + k] = be.cnt[k].gates; }
+    }
+    return 0;
+}
+
+// reference hierarchy of bvh #which as rebuilt by the product's flattener: {leaf,left,right,min,max} per node
+int emul_bvh_dump(const rt_scene_desc* d, uint32_t which, float* out, int cap_nodes)
+{
+    HostScene H;
+    H.spheres.assign(d->spheres, d->spheres + d->num_spheres);
+    H.planes.assign(d->planes, d->planes + d->num_planes);
+    H.triangles.assign(d->triangles, d->triangles + d->num_triangles);
+    H.meshes.assign(d->meshes, d->meshes + d->num_meshes);
+    H.multimeshes.assign(d->multimeshes, d->multimeshes + d->num_multimeshes);
+    H.bvhs.assign(d->bvhs, d->bvhs + d->num_bvhs);
+    H.bvh_leaves.assign(d->bvh_leaves, d->bvh_leaves + d->num_bvh_leaves);
+    H.scene.assign(d->scene, d->scene + d->num_scene);
+    H.materials.assign(d->materials, d->materials + d->num_materials);
+    H.textures.assign(d->textures, d->textures + d->num_textures);
+    H.lights.assign(d->lights, d->lights + d->num_lights);
+    H.ambient = d->ambient;
+    if (H.build() != 0 || which >= H.bvhs.size()) { g_err = H.error; return -1; }
+    std::vector<HostScene::RefNode> N;
+    if (H.reference_hierarchy(H.bvhs[which], N) != 0) return -1;
+    int n = (int)N.size();
+    for (int i = 0; i < n && i < cap_nodes; ++i) {
+        float* o = out + (size_t)i * 9;
+        o[0] = N[i].leaf ? 1.0f : 0.0f;
+        o[1] = N[i].leaf ? -1.0f : (float)N[i].left;
+        o[2] = N[i].leaf ? -1.0f : (float)N[i].right;
+        for (int k = 0; k < 3; ++k) { o[3 + k] = N[i].box.mn[k]; o[6 + k] = N[i].box.mx[k]; }
+    }
+    return n;
+}
+
+} // extern "C"

@@ -1,0 +1,80 @@
+"""Shared helpers of the test-suite."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from raytracer_amd import capi
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class Emul:
+    """ctypes wrapper of tests/emul/libemul.so (host emulation of the device pipeline)."""
+
+    def __init__(self, path):
+        self.lib = C.CDLL(path)
+        self.lib.emul_render.argtypes = [C.POINTER(capi.rt_scene_desc), C.POINTER(capi.rt_camera),
+                                         C.POINTER(capi.rt_params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.lib.emul_last_error.restype = C.c_char_p
+        self.lib.emul_bvh_dump.argtypes = [C.POINTER(capi.rt_scene_desc), C.c_uint32, C.c_void_p, C.c_int]
+
+    def render(self, flat, camera, params):
+        H, W = params.height, params.width
+        rgb = np.zeros((H, W, 3), np.float32)
+        pid = np.full((H, W), capi.RT_MISS, np.uint32)
+        t = np.zeros((H, W), np.float32)
+        cnt = np.zeros(13, np.uint64)
+        cam = camera.to_c()
+        rc = self.lib.emul_render(C.byref(flat.desc), C.byref(cam), C.byref(params), rgb.ctypes.data,
+                                  pid.ctypes.data, t.ctypes.data, cnt.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"emul_render failed ({rc}): {self.lib.emul_last_error().decode()}")
+        return rgb, pid, t, cnt
+
+    def bvh_dump(self, flat, which=0, cap=4096):
+        out = np.zeros((cap, 9), np.float32)
+        n = self.lib.emul_bvh_dump(C.byref(flat.desc), which, out.ctypes.data, cap)
+        if n < 0:
+            raise RuntimeError("emul_bvh_dump failed")
+        return out[:n]
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def quantize(rgb):
+    """saveToFile's truncating conversion (reference main.cpp:1847-1849)."""
+    return (np.asarray(rgb, np.float32) * np.float32(255)).astype(np.uint8)
+
+
+def lsb_diff(a, b):
+    return np.abs(quantize(a).astype(np.int32) - quantize(b).astype(np.int32))
+
+
+def psnr(a, b, peak=1.0):
+    mse = float(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2))
+    return 99.0 if mse == 0 else 10.0 * np.log10(peak * peak / mse)
+
+
+def small_scenes():
+    """(name, world, params) cases the oracle finishes in about a second each."""
+    from raytracer_amd import scenes, scene as S
+    out = []
+    w = scenes.default_scene(96, 96, sampler=S.Regular(1, 1), ao_samples=0)
+    out.append(("default_d1_flat", w, w.params()))
+    w = scenes.default_scene(96, 96, sampler=S.Regular(1, 1), ao_samples=4)
+    out.append(("default_d2_ao", w, w.params()))
+    w = scenes.default_scene(80, 60, sampler=S.Jitter(4, 83), ao_samples=4)
+    out.append(("default_jitter4_ao_nonsquare", w, w.params(seed=7)))
+    w = scenes.config4_scene(80, 45, spp=4)
+    out.append(("config4_depth8", w, w.params(max_depth=8, seed=3)))
+    w = scenes.config2_scene(96, 54)
+    out.append(("config2_primary_shadow", w, w.params()))
+    w = scenes.config3_scene(64, 36, spp=4, mesh_nu=48, mesh_nv=24)
+    out.append(("config3_textured_mesh", w, w.params(seed=11)))
+    w = scenes.config5_scene(64, 36, spp=1, instances=9, mesh_nu=12, mesh_nv=8)
+    out.append(("config5_instanced", w, w.params(seed=5)))
+    return out
