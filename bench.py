@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the render path on config 3 (4K, 16 jittered spp + 4x4 AO, textured BVH mesh).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step is one full frame.  With N > 1 every rank (one process per GPU) renders the 64x64 tiles
+t with t % N == rank into a compact slab; slabs are gathered to rank 0 over RCCL and scattered
+into the frame there.  Total work is fixed as N grows (strong scaling).  Rank 0 prints one JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--spp", type=int, default=16)
+    ap.add_argument("--mesh-nu", type=int, default=700)
+    ap.add_argument("--mesh-nv", type=int, default=360)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-crop", type=int, default=32, help="edge of the centre crop timed on the CPU")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import capi, scenes
+    from raytracer_amd.render import Renderer
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world_size:
+        if world_size == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    distributed = world_size > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        dist.init_process_group("nccl", device_id=dev)
+
+    world = scenes.config3_scene(args.width, args.height, args.spp, args.mesh_nu, args.mesh_nv)
+    flat = world.flatten()
+    ntri = int(flat.arrays["triangles"].shape[0])
+    r = Renderer(local_rank)
+    r.upload(flat)
+    params = world.params(seed=1)
+    params.tile_rank, params.tile_world = rank, world_size
+    W, H = args.width, args.height
+
+    owned = r.owned_tiles(params, rank, world_size)
+    max_owned = r.owned_tiles(params, 0, world_size)
+    if distributed:
+        slab = torch.zeros((max_owned, capi.RT_TILE * capi.RT_TILE, 3), dtype=torch.float32, device=dev)
+        out = slab
+        gather_list = [torch.zeros_like(slab) for _ in range(world_size)] if rank == 0 else None
+        frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev) if rank == 0 else None
+    else:
+        frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+        out = frame
+
+    def step(flags=0, stats=None):
+        params.flags = flags
+        # stream=None: the library's own stream, and the call returns when the frame is complete
+        r.render_device(world.camera, params, out.data_ptr(), None, None, stats, None)
+        if distributed:
+            dist.gather(slab, gather_list, dst=0)
+            if rank == 0:
+                for src in range(world_size):
+                    r.unpack_tiles(gather_list[src].data_ptr(), params, src, world_size, frame.data_ptr(), None)
+
+    def sync():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # untimed: ray counts and traversal counters (deterministic per frame), also the first warm-up
+    st_count = capi.rt_stats()
+    step(capi.RT_FLAG_STATS, st_count)
+    for _ in range(max(0, args.warmup - 1)):
+        step()
+    rays_rank = st_count.rays
+
+    kernel_ms = np.zeros(capi.RT_K_COUNT)
+    launches = np.zeros(capi.RT_K_COUNT)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = capi.rt_stats()
+        step(capi.RT_FLAG_TIMING, st)
+        kernel_ms += np.array(list(st.ms_kernel))
+        launches += np.array(list(st.launches))
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    tot = torch.tensor([elapsed, float(rays_rank)], dtype=torch.float64, device=dev)
+    if distributed:
+        tmax = tot.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tot.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0]); rays_total = float(tsum[1])
+    else:
+        rays_total = float(rays_rank)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = rays_total / (ms_per_step * 1e-3) / 1e6
+        # roofline of the dominant kernel (ambient-occlusion traversal), rank 0's launches:
+        # algorithmic bytes per ray B = 96 + 64*V + 48*T (V,T from the counting pass)
+        ao_rays = float(st_count.rays_ao)
+        V = st_count.nodes[2] / max(1.0, ao_rays)
+        T = st_count.tris[2] / max(1.0, ao_rays)
+        b_ray = 96.0 + 64.0 * V + 48.0 * T
+        k = capi.RT_K_NAMES.index("ao")
+        ao_ms = kernel_ms[k] / args.steps
+        ao_launches = launches[k] / args.steps
+        achieved = (ao_rays * b_ray) / (ao_ms * 1e-3) / 1e9 if ao_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_ao_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {
+            "bound": "hbm", "kernel": "k_ao", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "bytes_per_ray": round(b_ray, 1), "nodes_per_ray": round(V, 2), "tris_per_ray": round(T, 2),
+            "rays_per_launch": round(ao_rays / max(1.0, ao_launches), 1), "avg_launch_ms": round(ao_ms / max(1.0, ao_launches), 4),
+            "mrays_per_s_in_kernel": round(ao_rays / (ao_ms * 1e-3) / 1e6, 1) if ao_ms > 0 else None,
+        }
+        line = {
+            "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world_size,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"config3: {W}x{H}, {args.spp} jittered spp + 4x4 ambient occlusion, room + textured "
+                                   f"{ntri}-triangle BVH mesh, 1 point light", "rays_per_frame": int(rays_total),
+                       "parallelism": f"tiles64 x {world_size} gpu"},
+            "kernel_ms_per_step": {n: round(float(kernel_ms[i]) / args.steps, 3) for i, n in enumerate(capi.RT_K_NAMES)},
+            "roofline": roofline,
+        }
+        if world_size == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(world, flat, args)
+        print(json.dumps(line), flush=True)
+    r.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(world, flat, args):
+    """The reference itself (oracle/_ref, built from /root/reference in the build container) — or,
+    when that library is absent, our C restatement — timed on this host on a centre crop of the
+    same scene at 1 spp (the reference algorithm scans every triangle of a mesh per ray)."""
+    from oracle import bindings
+    from raytracer_amd import capi
+    nthreads = min(16, os.cpu_count() or 1)
+    if bindings.RefOracle.available():
+        orc, kind = bindings.RefOracle(), "reference"
+    else:
+        orc, kind = bindings.PortOracle(), "port"
+    c = args.cpu_crop
+    p = world.params(seed=1)
+    p.num_samples = 1
+    p.x0, p.x1 = args.width // 2 - c // 2, args.width // 2 - c // 2 + c
+    p.y0, p.y1 = args.height // 2 - c // 2, args.height // 2 - c // 2 + c
+    res = orc.render(flat, world.camera, p, rng_mode=1, nthreads=nthreads, ids=False)
+    return {"value": round(res.rays / res.seconds / 1e6, 4), "unit": "Mrays/s", "cores": nthreads, "kind": kind,
+            "sample": f"{c}x{c} px centre crop of the same frame at 1 spp (jitter + 4x4 AO on), {res.rays} rays in {res.seconds:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()
