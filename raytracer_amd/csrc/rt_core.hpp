@@ -74,7 +74,7 @@ struct DScene {
     const GateNode* gates; uint32_t num_gates;
     const q4* planes;    // 2 / plane : {point, bits(material)} {normal, 0}
     const q4* spheres;   // 2 / sphere: {centre, radius} {radius^2, bits(material), 0, 0}
-    const q4* tris;      // 3 / slot  : {v0, bits(global tri)} {e1=v1-v0, bits(material)} {e2=v2-v0, bits(rank offset)}
+    const q4* tris;      // 3 / slot  : {v0, bits(global tri)} {e1=v1-v0, bits(material)} {e2=v2-v0, bits(rank = reference visiting order)}
     const q4* tri_attr;  // 2 / global triangle: {uv0, uv1} {uv2, 0, 0}
     const q4* nodes;     // 4 / BVH2 node (64 B): both child boxes + child refs
     const DMaterial* materials;
@@ -85,6 +85,7 @@ struct DScene {
     uint32_t prim_base_sphere, prim_base_tri;
     float cull_pad;      // conservative padding of the BVH culling test, relative (see bvh_traverse)
     float extent;        // largest |coordinate| of the scene
+    uint32_t debug;      // experiment switches (0 in production)
 };
 
 // BVH child reference: bit31 = leaf, bits 28..30 = triangle count-1, bits 0..27 = first slot
@@ -94,6 +95,7 @@ struct Counters { uint32_t nodes, tris, gates; };
 
 struct Stack { uint32_t* p; uint32_t stride; };  // entry i lives at p[i*stride] (LDS: stride = threads per block)
 #define RT_STACK_DEPTH 32
+#define RT_PENDING_MAX 2   // deferred mesh roots before the drain loop is forced (builder depth bound = 30)
 
 struct Hit { float t; uint32_t prim; float u, v; uint32_t rank; };
 
@@ -218,54 +220,57 @@ RT_FN bool cull_box(const RayCull& c, float mnx, float mny, float mnz, float mxx
 }
 
 template <bool STATS, bool ANYHIT>
-RT_FN bool bvh_traverse(const DScene& S, const GateNode& g, f3 o, f3 d, const RayCull& rc, Hit& best,
-                        Stack st, Counters& cnt)
+RT_FN bool bvh_drain(const DScene& S, f3 o, f3 d, const RayCull& rc, Hit& best, Stack st, uint32_t& sp, Counters& cnt)
 {
-    uint32_t sp = 0;
-    uint32_t cur = g.a;
+    // Pops references until the stack is empty.  The stack holds the roots of every Mesh whose
+    // reference gate passed plus deferred children (inner nodes and leaves alike), so all lanes
+    // of a wave sit in this one loop together.  "while-while" form: every lane first descends
+    // through inner nodes until it holds a leaf (or nothing), then the wave tests leaf triangles
+    // together, so the expensive exact triangle test is not re-issued on every node step.
     bool found = false;
-    for (;;) {
-        const q4* n = S.nodes + (size_t)cur * 4;
-        q4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-        if (STATS) cnt.nodes++;
-        uint32_t refs[2] = {f2u(n3.x), f2u(n3.y)};
-        float tn[2];
-        bool hit[2];
-        hit[0] = refs[0] != REF_NONE && cull_box(rc, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, best.t, tn[0]);
-        hit[1] = refs[1] != REF_NONE && cull_box(rc, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, best.t, tn[1]);
-        uint32_t next[2] = {REF_NONE, REF_NONE};
-        for (int c = 0; c < 2; ++c) {
-            if (!hit[c]) continue;
-            if (refs[c] & REF_LEAF) {
-                uint32_t first = refs[c] & 0x0FFFFFFFu, count = ((refs[c] >> 28) & 7u) + 1u;
-                for (uint32_t i = 0; i < count; ++i) {
-                    const q4* T = S.tris + (size_t)(first + i) * 3;
-                    q4 a = T[0], b = T[1], e = T[2];
-                    if (STATS) cnt.tris++;
-                    float t, u, v;
-                    if (tri_t(xyz(a), xyz(b), xyz(e), o, d, t, u, v)) {
-                        uint32_t rank = g.rank + f2u(e.w);
-                        if (closer(t, rank, best)) {
-                            best.t = t; best.prim = H_TRI | (first + i); best.u = u; best.v = v; best.rank = rank;
-                            found = true;
-                            if (ANYHIT) return true;
-                        }
-                    }
-                }
+    if (sp == 0) return false;
+    if (S.debug & 1u) { sp = 0; return false; }
+    uint32_t cur = st.p[(--sp) * st.stride];
+    while (cur != REF_NONE) {
+        while (!(cur & REF_LEAF)) {   // cur is an inner node (REF_NONE has bit 31 clear but never gets here: see pops)
+            const q4* n = S.nodes + (size_t)cur * 4;
+            q4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            if (STATS) cnt.nodes++;
+            uint32_t r0 = f2u(n3.x), r1 = f2u(n3.y);
+            float t0, t1;
+            bool h0 = r0 != REF_NONE && cull_box(rc, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, best.t, t0);
+            bool h1 = r1 != REF_NONE && cull_box(rc, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, best.t, t1);
+            if (h0 && h1) {
+                bool swap = t1 < t0;
+                uint32_t nearc = swap ? r1 : r0, farc = swap ? r0 : r1;
+                if (sp < RT_STACK_DEPTH) st.p[(sp++) * st.stride] = farc;  // depth is bounded by the builder
+                cur = nearc;
+            } else if (h0) {
+                cur = r0;
+            } else if (h1) {
+                cur = r1;
             } else {
-                next[c] = refs[c];
+                if (sp == 0) { cur = REF_NONE; break; }
+                cur = st.p[(--sp) * st.stride];
             }
         }
-        if (next[0] != REF_NONE && next[1] != REF_NONE) {
-            bool swap = tn[1] < tn[0];
-            uint32_t nearc = swap ? next[1] : next[0], farc = swap ? next[0] : next[1];
-            if (sp < RT_STACK_DEPTH) st.p[(sp++) * st.stride] = farc;  // depth is bounded by the builder
-            cur = nearc;
-        } else if (next[0] != REF_NONE) {
-            cur = next[0];
-        } else if (next[1] != REF_NONE) {
-            cur = next[1];
-        } else {
+        if (cur == REF_NONE) break;
+        {   // cur is a leaf: up to 8 triangles stored contiguously
+            uint32_t first = cur & 0x0FFFFFFFu, count = ((cur >> 28) & 7u) + 1u;
+            for (uint32_t i = 0; i < count; ++i) {
+                const q4* T = S.tris + (size_t)(first + i) * 3;
+                q4 a = T[0], b = T[1], e = T[2];
+                if (STATS) cnt.tris++;
+                float t, u, v;
+                if (tri_t(xyz(a), xyz(b), xyz(e), o, d, t, u, v)) {
+                    uint32_t rank = f2u(e.w);
+                    if (closer(t, rank, best)) {
+                        best.t = t; best.prim = H_TRI | (first + i); best.u = u; best.v = v; best.rank = rank;
+                        found = true;
+                        if (ANYHIT) { sp = 0; return true; }
+                    }
+                }
+            }
             if (sp == 0) break;
             cur = st.p[(--sp) * st.stride];
         }
@@ -284,8 +289,9 @@ RT_FN void trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& shad
     best.t = tmax; best.prim = H_MISS; best.u = 0; best.v = 0; best.rank = 0;
     RayCull rc = make_cull(S, o, d);
     bool shadowed = false, transparentOnly = true;
+    if (S.debug & 2u) { shadow = 1.0f; return; }
     uint32_t cur_item = 0;
-    uint32_t i = 0;
+    uint32_t i = 0, sp = 0;
     const uint32_t n = S.num_gates;
     while (i < n) {
         const GateNode g = S.gates[i];
@@ -340,18 +346,29 @@ RT_FN void trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& shad
             i++;
             break;
         }
-        default: { // G_MESH
+        default: { // G_MESH: gate, then defer its triangle BVH to the shared drain loop
             if (STATS) cnt.gates++;
             if (box_intersects(g.mn, g.mx, o, d)) {
-                if (MODE == 1 && S.item_opaque[g.item]) {
-                    if (bvh_traverse<STATS, true>(S, g, o, d, rc, best, st, cnt)) { shadowed = true; transparentOnly = false; i = n; break; }
-                } else {
-                    bvh_traverse<STATS, false>(S, g, o, d, rc, best, st, cnt);
+                st.p[(sp++) * st.stride] = g.a;
+                if (sp >= RT_PENDING_MAX) {
+                    if (MODE == 1 && S.item_opaque[g.item]) {
+                        if (bvh_drain<STATS, true>(S, o, d, rc, best, st, sp, cnt)) { shadowed = true; transparentOnly = false; i = n; break; }
+                    } else {
+                        bvh_drain<STATS, false>(S, o, d, rc, best, st, sp, cnt);
+                    }
                 }
             }
             i++;
             break;
         }
+        }
+        // end of the walk, or (shadow query) end of a world->scene entry: drain the deferred meshes
+        if (sp > 0 && (i >= n || (MODE == 1 && S.gates[i].item != cur_item))) {
+            if (MODE == 1 && S.item_opaque[cur_item]) {
+                if (bvh_drain<STATS, true>(S, o, d, rc, best, st, sp, cnt)) { shadowed = true; transparentOnly = false; i = n; }
+            } else {
+                bvh_drain<STATS, false>(S, o, d, rc, best, st, sp, cnt);
+            }
         }
     }
     if (MODE == 1) {

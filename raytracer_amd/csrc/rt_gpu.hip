@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -444,6 +445,7 @@ int rt_scene_commit(rt_scene* s)
     D.prim_base_tri = (uint32_t)(H.planes.size() + H.spheres.size());
     D.cull_pad = 1.0f / 262144.0f;
     D.extent = H.extent;
+    D.debug = getenv("RT_DEBUG") ? (uint32_t)atoi(getenv("RT_DEBUG")) : 0u;
     s->committed = true;
     return RT_OK;
 }

@@ -229,8 +229,11 @@ RT_FN void shadow_item(const DScene& S, const RenderArgs& A, const Batch& B, int
 template <bool STATS>
 RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, Stack st, Counters& cnt)
 {
+    // stratum-major order: a wave traces the same stratum (x,y) of 64 neighbouring hits, whose
+    // rays leave nearby points in similar directions, instead of the 16 directions of 4 hits
+    uint32_t nslots = B.counters[C_AO + depth];
     uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
-    uint32_t slot = idx / n2, k = idx % n2;
+    uint32_t slot = idx % nslots, k = idx / nslots;
     uint32_t p = B.ao_queue[slot];
     PathPix px = path_of(A, p);
     q4 o4 = B.ray_o[depth & 1][p], d4 = B.ray_d[depth & 1][p];
@@ -241,7 +244,7 @@ RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int dep
     ao_ray(S.ambient, P, N, A.seed, px.key, px.j, a, k, o, dir);
     Hit h; float sh;
     trace<0, STATS>(S, o, dir, S.ambient.occlusion_dist, h, sh, st, cnt);
-    B.ao_t[idx] = h.t;   // stays occlusion_dist when nothing closer was found
+    B.ao_t[(size_t)slot * n2 + k] = h.t;   // stays occlusion_dist when nothing closer was found
 }
 
 // world->ambient->L(sr): Light::L, or Ambient::L's reduction of the n*n distances in x,y order

@@ -175,13 +175,13 @@ int HostScene::reference_hierarchy(const rt_bvh& b, std::vector<RefNode>& H)
     return RT_OK;
 }
 
-uint32_t HostScene::add_triangle_slot(uint32_t gid, uint32_t rank_off)
+uint32_t HostScene::add_triangle_slot(uint32_t gid, uint32_t rank)
 {
     const rt_triangle& t = triangles[gid];
     uint32_t slot = (uint32_t)(tris4.size() / 3);
     q4 a = {t.v0[0], t.v0[1], t.v0[2], u2f(gid)};
     q4 b = {t.v1[0] - t.v0[0], t.v1[1] - t.v0[1], t.v1[2] - t.v0[2], u2f((uint32_t)t.material)};
-    q4 c = {t.v2[0] - t.v0[0], t.v2[1] - t.v0[1], t.v2[2] - t.v0[2], u2f(rank_off)};
+    q4 c = {t.v2[0] - t.v0[0], t.v2[1] - t.v0[1], t.v2[2] - t.v0[2], u2f(rank)};
     tris4.push_back(a); tris4.push_back(b); tris4.push_back(c);
     return slot;
 }
@@ -200,9 +200,10 @@ inline float half_area(const float* mn, const float* mx)
 }
 } // namespace
 
-uint32_t HostScene::mesh_bvh(uint32_t mesh)
+uint32_t HostScene::mesh_bvh(uint32_t mesh, uint32_t rank_base)
 {
-    if (mesh_root_[mesh] != 0xFFFFFFFFu) return mesh_root_[mesh];
+    // triangle records carry their absolute rank, so a Mesh reachable through two gate nodes gets two BVH copies
+    if (mesh_root_[mesh] != 0xFFFFFFFFu && mesh_rank_[mesh] == rank_base) return mesh_root_[mesh];
     const rt_mesh& m = meshes[mesh];
     std::vector<BuildTri> T(m.num_triangles);
     for (uint32_t k = 0; k < m.num_triangles; ++k) {
@@ -223,7 +224,7 @@ uint32_t HostScene::mesh_bvh(uint32_t mesh)
     auto make_leaf = [&](uint32_t lo, uint32_t hi) -> uint32_t {
         uint32_t first = 0;
         for (uint32_t i = lo; i < hi; ++i) {
-            uint32_t s = add_triangle_slot(T[i].gid, T[i].gid - m.first_triangle);
+            uint32_t s = add_triangle_slot(T[i].gid, rank_base + (T[i].gid - m.first_triangle));
             if (i == lo) first = s;
         }
         return REF_LEAF | ((hi - lo - 1u) << 28) | first;
@@ -316,7 +317,7 @@ uint32_t HostScene::mesh_bvh(uint32_t mesh)
         root = build(0, m.num_triangles, 0);
     }
     bvh_max_depth = std::max(bvh_max_depth, max_depth_seen);
-    mesh_root_[mesh] = root;
+    mesh_root_[mesh] = root; mesh_rank_[mesh] = rank_base;
     return root;
 }
 
@@ -324,7 +325,7 @@ void HostScene::emit_mesh(uint32_t mesh, uint32_t item, uint32_t rank_base)
 {
     GateNode g{};
     std::memcpy(g.mn, mesh_box_[mesh].mn, 12); std::memcpy(g.mx, mesh_box_[mesh].mx, 12);
-    g.kind = G_MESH; g.a = mesh_bvh(mesh); g.rank = rank_base; g.prim = meshes[mesh].first_triangle; g.item = item;
+    g.kind = G_MESH; g.a = mesh_bvh(mesh, rank_base); g.rank = rank_base; g.prim = meshes[mesh].first_triangle; g.item = item;
     g.skip = (uint32_t)gates.size() + 1;
     gates.push_back(g);
 }
@@ -368,7 +369,7 @@ void HostScene::emit_shape(const rt_shape_ref& r, uint32_t item, uint32_t rank_b
     switch (r.kind) {
     case RT_SHAPE_PLANE: g.kind = G_PLANE; g.a = r.index; g.skip = (uint32_t)gates.size() + 1; gates.push_back(g); break;
     case RT_SHAPE_SPHERE: g.kind = G_SPHERE; g.a = r.index; g.skip = (uint32_t)gates.size() + 1; gates.push_back(g); break;
-    case RT_SHAPE_TRIANGLE: g.kind = G_TRI; g.a = add_triangle_slot(r.index, 0); g.skip = (uint32_t)gates.size() + 1; gates.push_back(g); break;
+    case RT_SHAPE_TRIANGLE: g.kind = G_TRI; g.a = add_triangle_slot(r.index, rank_base); g.skip = (uint32_t)gates.size() + 1; gates.push_back(g); break;
     case RT_SHAPE_MESH: emit_mesh(r.index, item, rank_base); break;
     case RT_SHAPE_MULTIMESH: {
         size_t me = gates.size();
@@ -433,6 +434,7 @@ int HostScene::build()
         for (uint32_t k = 0; k < multimeshes[i].num_meshes; ++k) box_merge(mm_box_[i], mesh_box_[multimeshes[i].first_mesh + k]);
     }
     mesh_root_.assign(meshes.size(), 0xFFFFFFFFu);
+    mesh_rank_.assign(meshes.size(), 0);
 
     for (auto& p : planes) {
         planes4.push_back({p.point[0], p.point[1], p.point[2], u2f((uint32_t)p.material)});

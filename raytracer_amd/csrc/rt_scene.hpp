@@ -52,15 +52,15 @@ struct HostScene {
 
 private:
     std::vector<Aabb> mesh_box_, mm_box_;
-    std::vector<uint32_t> mesh_root_;          // triangle-BVH root per mesh (0xFFFFFFFF = not built yet)
+    std::vector<uint32_t> mesh_root_, mesh_rank_; // triangle-BVH root per mesh (0xFFFFFFFF = not built yet) and the rank base it was built for
     int validate();
     int shape_box(const rt_shape_ref& r, Aabb& out);
     uint32_t prim_count(const rt_shape_ref& r);
-    uint32_t mesh_bvh(uint32_t mesh);
+    uint32_t mesh_bvh(uint32_t mesh, uint32_t rank_base);
     void emit_shape(const rt_shape_ref& r, uint32_t item, uint32_t rank_base);
     void emit_mesh(uint32_t mesh, uint32_t item, uint32_t rank_base);
     int emit_bvh(uint32_t bvh, uint32_t item, uint32_t rank_base);
-    uint32_t add_triangle_slot(uint32_t gid, uint32_t rank_off);
+    uint32_t add_triangle_slot(uint32_t gid, uint32_t rank);
     bool subtree_opaque(const rt_shape_ref& r);
 };
 

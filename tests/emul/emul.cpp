@@ -82,7 +82,7 @@ int emul_render(const rt_scene_desc* d, const rt_camera* cam, const rt_params* p
     S.item_opaque = H.item_opaque.data(); S.num_items = (uint32_t)H.item_opaque.size();
     S.ambient = H.ambient;
     S.prim_base_sphere = (uint32_t)H.planes.size(); S.prim_base_tri = (uint32_t)(H.planes.size() + H.spheres.size());
-    S.cull_pad = 1.0f / 262144.0f; S.extent = H.extent;
+    S.cull_pad = 1.0f / 262144.0f; S.extent = H.extent; S.debug = 0;
 
     RenderArgs A{};
     A.cam = make_camera(*cam);
