@@ -119,29 +119,33 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = rays_total / (ms_per_step * 1e-3) / 1e6
-        # roofline of the dominant kernel (ambient-occlusion traversal), rank 0's launches:
-        # algorithmic bytes per ray B = 96 + 64*V + 48*T (V,T from the counting pass)
-        ao_rays = float(st_count.rays_ao)
-        V = st_count.nodes[2] / max(1.0, ao_rays)
-        T = st_count.tris[2] / max(1.0, ao_rays)
+        # roofline of the dominant kernel = the compacted triangle-BVH traversal of the ambient-
+        # occlusion rays (k_bvh<AO>), rank 0's launches.  Algorithmic bytes per ray it processes:
+        # B = 96 + 64*V + 48*T (ray+hit records, V 64-byte nodes, T 48-byte triangles;
+        # V and T come from the counting pass and count cache hits too).
+        k = capi.RT_K_NAMES.index("ao_bvh")
+        units = float(st_count.bvh_rays[2])
+        V = st_count.nodes[2] / max(1.0, units)
+        T = st_count.tris[2] / max(1.0, units)
         b_ray = 96.0 + 64.0 * V + 48.0 * T
-        k = capi.RT_K_NAMES.index("ao")
-        ao_ms = kernel_ms[k] / args.steps
-        ao_launches = launches[k] / args.steps
-        achieved = (ao_rays * b_ray) / (ao_ms * 1e-3) / 1e9 if ao_ms > 0 else 0.0
+        k_ms = kernel_ms[k] / args.steps
+        k_launches = launches[k] / args.steps
+        achieved = (units * b_ray) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_ao_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("k_bvh_ao_bytes_per_launch")
             except Exception:
                 traffic = None
+        ao_rays = float(st_count.rays_ao)
         roofline = {
-            "bound": "hbm", "kernel": "k_ao", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": "k_bvh<AO>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "bytes_per_ray": round(b_ray, 1), "nodes_per_ray": round(V, 2), "tris_per_ray": round(T, 2),
-            "rays_per_launch": round(ao_rays / max(1.0, ao_launches), 1), "avg_launch_ms": round(ao_ms / max(1.0, ao_launches), 4),
-            "mrays_per_s_in_kernel": round(ao_rays / (ao_ms * 1e-3) / 1e6, 1) if ao_ms > 0 else None,
+            "rays_per_launch": round(units / max(1.0, k_launches), 1), "avg_launch_ms": round(k_ms / max(1.0, k_launches), 4),
+            "mrays_per_s_in_kernel": round(units / (k_ms * 1e-3) / 1e6, 1) if k_ms > 0 else None,
+            "ao_rays_total": int(ao_rays), "ao_rays_needing_bvh": int(units),
         }
         line = {
             "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world_size,

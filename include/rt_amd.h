@@ -152,13 +152,15 @@ typedef struct rt_params {
 #define RT_FLAG_TIMING     2u  /* bracket every launch with HIP events (rt_stats.ms_*)      */
 #define RT_TILE 64             /* edge of the tile that is the unit of the multi-GPU split  */
 
-enum { RT_K_RAYGEN = 0, RT_K_TRACE, RT_K_PREP, RT_K_SHADOW, RT_K_AO, RT_K_SHADE, RT_K_RESOLVE, RT_K_COUNT };
+enum { RT_K_RAYGEN = 0, RT_K_TRACE, RT_K_TRACE_BVH, RT_K_PREP, RT_K_SHADOW, RT_K_AO, RT_K_AO_BVH, RT_K_SHADE, RT_K_RESOLVE, RT_K_COUNT };
 
 typedef struct rt_stats {
     uint64_t rays_primary, rays_shadow, rays_ao, rays_bounce; /* closest-hit queries traced */
     /* RT_FLAG_STATS only: BVH nodes fetched / triangles tested / reference-level gate boxes
      * tested, per ray class {closest(primary+bounce), shadow, ao} */
     uint64_t nodes[3], tris[3], gates[3];
+    uint64_t bvh_rays[3];            /* rays of each class that had at least one Mesh gate pass and were
+                                        traversed by the compacted triangle-BVH kernel                */
     double   ms_total;               /* hipEvent time of the whole render on its stream      */
     double   ms_kernel[RT_K_COUNT];  /* RT_FLAG_TIMING: summed per kernel class              */
     uint32_t launches[RT_K_COUNT];

@@ -18,7 +18,7 @@ RT_LIGHT_POINT, RT_LIGHT_DIRECTIONAL = range(2)
 RT_SAMPLER_REGULAR, RT_SAMPLER_JITTER, RT_SAMPLER_RANDOM = range(3)
 RT_FLAG_STATS, RT_FLAG_TIMING = 1, 2
 RT_TILE = 64
-RT_K_NAMES = ["raygen", "trace", "prep", "shadow", "ao", "shade", "resolve"]
+RT_K_NAMES = ["raygen", "trace", "trace_bvh", "prep", "shadow", "ao", "ao_bvh", "shade", "resolve"]
 RT_K_COUNT = len(RT_K_NAMES)
 RT_MISS = 0xFFFFFFFF
 
@@ -84,7 +84,7 @@ class rt_params(C.Structure):
 class rt_stats(C.Structure):
     _fields_ = [
         ("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_ao", C.c_uint64), ("rays_bounce", C.c_uint64),
-        ("nodes", C.c_uint64 * 3), ("tris", C.c_uint64 * 3), ("gates", C.c_uint64 * 3),
+        ("nodes", C.c_uint64 * 3), ("tris", C.c_uint64 * 3), ("gates", C.c_uint64 * 3), ("bvh_rays", C.c_uint64 * 3),
         ("ms_total", C.c_double), ("ms_kernel", C.c_double * RT_K_COUNT),
         ("launches", C.c_uint32 * RT_K_COUNT), ("batches", C.c_uint32),
     ]

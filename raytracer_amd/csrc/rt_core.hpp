@@ -95,6 +95,7 @@ struct Counters { uint32_t nodes, tris, gates; };
 
 struct Stack { uint32_t* p; uint32_t stride; };  // entry i lives at p[i*stride] (LDS: stride = threads per block)
 #define RT_STACK_DEPTH 32
+#define RT_DEFER_ROOTS 8   // mesh roots one queued BVH item can carry
 #define RT_PENDING_MAX 2   // deferred mesh roots before the drain loop is forced (builder depth bound = 30)
 
 struct Hit { float t; uint32_t prim; float u, v; uint32_t rank; };
@@ -283,13 +284,16 @@ RT_FN bool bvh_drain(const DScene& S, f3 o, f3 d, const RayCull& rc, Hit& best, 
 //         1457-1460, 1548-1551) with rec.t starting at tmax.
 // MODE 1: Material::shadowed (main.cpp:40-76): closest hit per world->scene entry with
 //         rec.t = tmax; returns 1, 0 or 0.8 in `shadow`.
-template <int MODE, bool STATS>
-RT_FN void trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& shadow, Stack st, Counters& cnt)
+// DEFER (closest-hit only): Mesh gates that pass are not traversed here; their BVH roots are left
+//         on the stack (up to RT_DEFER_ROOTS, more are drained inline) and the count is returned,
+//         so the caller can queue the ray for the compacted BVH kernel (bvh_item below).
+template <int MODE, bool STATS, bool DEFER = false>
+RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& shadow, Stack st, Counters& cnt)
 {
     best.t = tmax; best.prim = H_MISS; best.u = 0; best.v = 0; best.rank = 0;
     RayCull rc = make_cull(S, o, d);
     bool shadowed = false, transparentOnly = true;
-    if (S.debug & 2u) { shadow = 1.0f; return; }
+    if (S.debug & 2u) { shadow = 1.0f; return 0; }
     uint32_t cur_item = 0;
     uint32_t i = 0, sp = 0;
     const uint32_t n = S.num_gates;
@@ -350,7 +354,7 @@ RT_FN void trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& shad
             if (STATS) cnt.gates++;
             if (box_intersects(g.mn, g.mx, o, d)) {
                 st.p[(sp++) * st.stride] = g.a;
-                if (sp >= RT_PENDING_MAX) {
+                if (sp >= (DEFER ? RT_DEFER_ROOTS : RT_PENDING_MAX)) {
                     if (MODE == 1 && S.item_opaque[g.item]) {
                         if (bvh_drain<STATS, true>(S, o, d, rc, best, st, sp, cnt)) { shadowed = true; transparentOnly = false; i = n; break; }
                     } else {
@@ -363,7 +367,7 @@ RT_FN void trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& shad
         }
         }
         // end of the walk, or (shadow query) end of a world->scene entry: drain the deferred meshes
-        if (sp > 0 && (i >= n || (MODE == 1 && S.gates[i].item != cur_item))) {
+        if (!DEFER && sp > 0 && (i >= n || (MODE == 1 && S.gates[i].item != cur_item))) {
             if (MODE == 1 && S.item_opaque[cur_item]) {
                 if (bvh_drain<STATS, true>(S, o, d, rc, best, st, sp, cnt)) { shadowed = true; transparentOnly = false; i = n; }
             } else {
@@ -384,6 +388,7 @@ RT_FN void trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& shad
         }
         shadow = shadowed ? (transparentOnly ? 0.8f : 0.0f) : 1.0f;
     }
+    return sp;
 }
 
 // ---- camera + pixel samples -----------------------------------------------------------------------

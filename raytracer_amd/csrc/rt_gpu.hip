@@ -89,6 +89,142 @@ __global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B
     flush_counters<STATS>(cnt, B.stats, 2);
 }
 
+// Compacted triangle-BVH traversal (the dominant kernel).  Persistent waves with three ideas:
+//  * refill: a lane that finishes its ray fetches the next one from the queue (the wave takes
+//    RT_BVH_CHUNK consecutive items with one atomic; a single hot counter word serves only ~90
+//    returning atomics per microsecond: MI355X_MICROARCH.md row 'dequeue'), so short rays do not
+//    idle their lanes until the longest ray of the wave is done;
+//  * decoupled node / triangle work: leaves met during the descent are parked in a small per-lane
+//    LDS queue instead of being tested on the spot, and every iteration the wave votes (ballot +
+//    popcount) for ONE kind of step — a 64-byte node fetch + two box tests, or one 48-byte
+//    triangle fetch + exact test — whichever more lanes are ready for;
+//  * the exact Moller-Trumbore test is evaluated branch-free (same operations, same order as
+//    tri_t(); only the early returns are folded into one predicate).
+// Results are identical to bvh_item()/bvh_drain() (rt_pipeline.hpp / rt_core.hpp), which the CPU
+// emulation runs: the closest hit does not depend on visiting order (ties resolved by rank).
+#define RT_BVH_CHUNK 512
+#define RT_REFILL_IDLE 16    // refill once this many lanes hold no ray
+#define RT_PEND 4            // parked leaves per lane
+template <bool AO, bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter, int next_counter)
+{
+    __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_BLOCK];
+    __shared__ uint32_t s_pend[RT_PEND * RT_BLOCK];
+    uint32_t n = B.counters[counter];
+    if (n > B.bq_cap) n = B.bq_cap;
+    uint32_t* next = &B.counters[next_counter];
+    uint32_t* stk = s_stack + threadIdx.x;
+    uint32_t* pend = s_pend + threadIdx.x;
+    Counters cnt{0, 0, 0};
+    const uint32_t lane = threadIdx.x & 63u;
+    f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
+    RayCull rc = {};
+    Hit best = {};
+    uint32_t sp = 0, cur = REF_NONE, dst = 0, npend = 0, tri_next = 0, tri_left = 0;
+    bool active = false, exhausted = false;
+    uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform
+    for (;;) {
+        // ---- retire finished rays -------------------------------------------------------------
+        if (active && cur == REF_NONE && npend == 0 && tri_left == 0) {
+            if (AO) B.ao_t[dst] = best.t;
+            else { const q4 r = {best.t, u2f(best.prim), best.u, best.v}; B.hit[dst] = r; }
+            active = false;
+        }
+        // ---- refill ---------------------------------------------------------------------------
+        const unsigned long long idle = __ballot(!active);
+        const uint32_t nidle = (uint32_t)__popcll(idle);
+        if (!exhausted && (nidle >= RT_REFILL_IDLE)) {
+            if (chunk_next >= chunk_end) {
+                uint32_t b0 = 0;
+                if (lane == 0) b0 = atomicAdd(next, (uint32_t)RT_BVH_CHUNK);
+                b0 = __shfl(b0, 0);
+                chunk_next = b0; chunk_end = b0 + RT_BVH_CHUNK < n ? b0 + RT_BVH_CHUNK : n;
+                if (b0 >= n) { exhausted = true; chunk_next = chunk_end = 0; }
+            }
+            const uint32_t base = chunk_next, lim = chunk_end;
+            chunk_next = base + nidle < lim ? base + nidle : lim;
+            if (!active) {
+                const uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (idx < lim) {   // items at or beyond the chunk end are left for the next refill
+                    const q4 a = B.bq_a[idx], b = B.bq_b[idx];
+                    o = xyz(a); d = xyz(b); dst = f2u(b.w);
+                    best.t = a.w; best.prim = H_MISS; best.rank = 0; best.u = 0; best.v = 0;
+                    if (!AO) { const q4 c = B.bq_c[idx]; best.prim = f2u(c.x); best.rank = f2u(c.y); best.u = c.z; best.v = c.w; }
+                    rc = make_cull(S, o, d);
+                    sp = 0; npend = 0; tri_left = 0;
+                    for (uint32_t k = 0; k < RT_DEFER_ROOTS; ++k) {
+                        const uint32_t r = B.bq_roots[(size_t)k * B.bq_cap + idx];
+                        if (r == REF_NONE) break;
+                        stk[(sp++) * RT_BLOCK] = r;
+                    }
+                    if (sp > 0) { cur = stk[(--sp) * RT_BLOCK]; active = true; }   // a slot without roots is a hole
+                }
+            }
+        }
+        // ---- vote for the kind of step ------------------------------------------------------------
+        const bool can_node = active && cur != REF_NONE && (!(cur & REF_LEAF) || npend < RT_PEND);
+        const bool can_tri = active && (tri_left > 0 || npend > 0);
+        const uint32_t n_node = (uint32_t)__popcll(__ballot(can_node));
+        const uint32_t n_tri = (uint32_t)__popcll(__ballot(can_tri));
+        if (n_node == 0 && n_tri == 0) {
+            if (__ballot(active) == 0ull && (exhausted || n == 0)) break;
+            continue;   // only finished rays (retired at the top) or an empty refill: go round again
+        }
+        if (n_node > n_tri) {
+            if (can_node) {
+                if (cur & REF_LEAF) {
+                    pend[(npend++) * RT_BLOCK] = cur;
+                    cur = sp == 0 ? (uint32_t)REF_NONE : stk[(--sp) * RT_BLOCK];
+                } else {
+                    const q4* nd = S.nodes + (size_t)cur * 4;
+                    const q4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+                    if (STATS) cnt.nodes++;
+                    const uint32_t r0 = f2u(n3.x), r1 = f2u(n3.y);
+                    float t0, t1;
+                    const bool h0 = r0 != REF_NONE && cull_box(rc, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, best.t, t0);
+                    const bool h1 = r1 != REF_NONE && cull_box(rc, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, best.t, t1);
+                    if (h0 && h1) {
+                        const bool swap = t1 < t0;
+                        if (sp < RT_STACK_DEPTH) stk[(sp++) * RT_BLOCK] = swap ? r0 : r1;
+                        cur = swap ? r1 : r0;
+                    } else if (h0) {
+                        cur = r0;
+                    } else if (h1) {
+                        cur = r1;
+                    } else {
+                        cur = sp == 0 ? (uint32_t)REF_NONE : stk[(--sp) * RT_BLOCK];
+                    }
+                }
+            }
+        } else {
+            if (can_tri) {
+                if (tri_left == 0) {
+                    const uint32_t ref = pend[(--npend) * RT_BLOCK];
+                    tri_next = ref & 0x0FFFFFFFu; tri_left = ((ref >> 28) & 7u) + 1u;
+                }
+                const q4* T = S.tris + (size_t)tri_next * 3;
+                const q4 a = T[0], b = T[1], e = T[2];
+                if (STATS) cnt.tris++;
+                // Triangle::intersectRay (reference main.cpp:713-739), branch-free
+                const f3 v0v1 = xyz(b), v0v2 = xyz(e);
+                const f3 pvec = cross(d, v0v2);
+                const float det = dot(v0v1, pvec);
+                const float invDet = 1.0f / det;
+                const f3 tvec = o - xyz(a);
+                const float u = dot(tvec, pvec) * invDet;
+                const f3 qvec = cross(tvec, v0v1);
+                const float v = dot(d, qvec) * invDet;
+                const float t = dot(v0v2, qvec) * invDet;
+                const bool ok = !(det < 0.000001f) && !(u < 0 || u > 1) && !(v < 0 || u + v > 1);
+                const uint32_t rank = f2u(e.w);
+                if (ok && closer(t, rank, best)) { best.t = t; best.prim = H_TRI | tri_next; best.u = u; best.v = v; best.rank = rank; }
+                tri_next++; tri_left--;
+            }
+        }
+    }
+    flush_counters<STATS>(cnt, B.stats, AO ? 2 : 0);
+}
+
 __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
 {
     const uint32_t n = depth == 0 ? fixed_n : B.counters[C_QUEUE + depth];
@@ -100,13 +236,16 @@ __global__ void __launch_bounds__(RT_BLOCK) k_resolve(DScene S, RenderArgs A, Ba
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) resolve_item(S, A, B, i);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const unsigned n2 = (unsigned)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
-        unsigned long long sh = 0, ao = 0, bo = 0;
+        unsigned long long sh = 0, ao = 0, bo = 0, bt = 0, ba = 0;
         for (int d = 0; d < levels_run; ++d) {
+            bt += B.counters[C_BQ + d] < B.bq_cap ? B.counters[C_BQ + d] : B.bq_cap;
+            ba += B.counters[C_BQA + d] < B.bq_cap ? B.counters[C_BQA + d] : B.bq_cap;
             sh += B.counters[C_SH + d];
             ao += (unsigned long long)B.counters[C_AO + d] * n2;
             if (d > 0) bo += B.counters[C_QUEUE + d];
         }
         B.stats[ST_SHADOW] += sh; B.stats[ST_AO] += ao; B.stats[ST_BOUNCE] += bo;
+        B.stats[ST_BVHRAYS + 0] += bt; B.stats[ST_BVHRAYS + 2] += ba;
     }
 }
 
@@ -216,6 +355,21 @@ struct GpuBackend {
             else hipLaunchKernelGGL(k_trace<false>, dim3(grid_d(d, n)), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
         });
     }
+    void bvh_trace(const RenderArgs& A, int d)
+    {
+        timed(RT_K_TRACE_BVH, [&] {
+            if (stats) hipLaunchKernelGGL((k_bvh<false, true>), dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, B, C_BQ + d, C_BQ_NEXT + d);
+            else hipLaunchKernelGGL((k_bvh<false, false>), dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, B, C_BQ + d, C_BQ_NEXT + d);
+        });
+    }
+    void bvh_ao(const RenderArgs& A, int d)
+    {
+        if (S.ambient.occlusion_samples <= 0) return;
+        timed(RT_K_AO_BVH, [&] {
+            if (stats) hipLaunchKernelGGL((k_bvh<true, true>), dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, B, C_BQA + d, C_BQA_NEXT + d);
+            else hipLaunchKernelGGL((k_bvh<true, false>), dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, B, C_BQA + d, C_BQA_NEXT + d);
+        });
+    }
     void prep(const RenderArgs& A, int d, uint32_t n) { timed(RT_K_PREP, [&] { hipLaunchKernelGGL(k_prep, dim3(grid_d(d, n)), dim3(RT_BLOCK), 0, stream, S, A, B, d, n); }); }
     void shadow(const RenderArgs& A, int d)
     {
@@ -257,6 +411,11 @@ size_t carve_batch(Batch& B, char* base, uint32_t P, int levels, uint32_t nl, ui
     B.lvl = (q4*)take(sizeof(q4) * (size_t)P * levels);
     B.lvl_ph = (float*)take(4ull * P * levels * (nl > 1 ? nl - 1 : 1));
     B.lvl_kind = (uint8_t*)take((size_t)P * levels);
+    B.bq_cap = P * (n2 ? n2 : 1);
+    B.bq_a = (q4*)take(sizeof(q4) * (size_t)B.bq_cap);
+    B.bq_b = (q4*)take(sizeof(q4) * (size_t)B.bq_cap);
+    B.bq_c = (q4*)take(sizeof(q4) * (size_t)P);
+    B.bq_roots = (uint32_t*)take(4ull * RT_DEFER_ROOTS * (size_t)B.bq_cap);
     return off;
 }
 } // namespace
@@ -560,7 +719,7 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
         }
         stats->rays_primary = prim * (uint64_t)A.spp;
         stats->rays_shadow = h[ST_SHADOW]; stats->rays_ao = h[ST_AO]; stats->rays_bounce = h[ST_BOUNCE];
-        for (int k = 0; k < 3; ++k) { stats->nodes[k] = h[ST_NODES + k]; stats->tris[k] = h[ST_TRIS + k]; stats->gates[k] = h[ST_GATES + k]; }
+        for (int k = 0; k < 3; ++k) { stats->nodes[k] = h[ST_NODES + k]; stats->tris[k] = h[ST_TRIS + k]; stats->gates[k] = h[ST_GATES + k]; stats->bvh_rays[k] = h[ST_BVHRAYS + k]; }
         float ms = 0.0f;
         HIPCHECK(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
         stats->ms_total = ms;

@@ -7,9 +7,11 @@
 //   raygen            [raytrace(): sampleUnitSquare + Camera::calculateRay, main.cpp:1633-1641]
 //   for depth d = 0 .. max_depth+1 over the per-depth path queue:
 //     trace           [for obj in world->scene: obj->hit(), main.cpp:1645-1648 / 1457-1460 / 1548-1551]
+//     bvh (trace)     [the Mesh::hit triangle loops of the rays whose gates passed, main.cpp:890-912, compacted]
 //     prep            [hit attributes; Reflective::rho / Transparency::rho ray set-up, main.cpp:1437-1468, 1525-1592]
 //     shadow          [Material::shadowed, main.cpp:40-76]
 //     ao              [Ambient::L's n x n rays, main.cpp:1361-1404]
+//     bvh (ao)        [their Mesh::hit triangle loops, compacted]
 //     shade           [Matte/Specular/Textured/Mirror/Refraction::shade, main.cpp:1143-1299, 1487-1511, 1607-1616]
 //   resolve           [per-level `L = clamp(local + child)` unwound deepest first; pixel average main.cpp:1656-1658]
 #pragma once
@@ -18,8 +20,8 @@
 namespace rt {
 
 enum : uint8_t { LK_NONE = 0, LK_TERMINAL = 1, LK_MIRROR = 2, LK_REFRACT = 3 };
-enum { C_QUEUE = 0, C_AO = 64, C_SH = 128, C_TOTAL = 192 };          // per-batch u32 counters
-enum { ST_SHADOW = 0, ST_AO = 1, ST_BOUNCE = 2, ST_NODES = 3, ST_TRIS = 6, ST_GATES = 9, ST_TOTAL = 12 }; // u64
+enum { C_QUEUE = 0, C_AO = 64, C_SH = 128, C_BQ = 192, C_BQA = 256, C_BQ_NEXT = 320, C_BQA_NEXT = 384, C_TOTAL = 448 };   // per-batch u32 counters, one per depth
+enum { ST_SHADOW = 0, ST_AO = 1, ST_BOUNCE = 2, ST_NODES = 3, ST_TRIS = 6, ST_GATES = 9, ST_BVHRAYS = 12, ST_TOTAL = 15 }; // u64
 #define RT_MAX_LEVELS 62
 
 struct Batch {
@@ -38,6 +40,12 @@ struct Batch {
     q4* lvl;               // [d*P + p]  TERMINAL: final colour; MIRROR: {ambient term, phong of light 0}
     float* lvl_ph;         // [(d*P + p)*(num_lights-1) + (l-1)] phong of lights 1..
     uint8_t* lvl_kind;     // [d*P + p]
+    // compacted BVH work queue, structure-of-arrays so a wave's appends and fetches are contiguous
+    q4* bq_a;              // {origin, closest t among the non-mesh primitives}
+    q4* bq_b;              // {direction, bits(dst)}
+    q4* bq_c;              // closest-hit queries only: {bits(prim), bits(rank), u, v} of that closest hit
+    uint32_t* bq_roots;    // [k * bq_cap + item]: mesh-BVH roots, terminated by REF_NONE when fewer than RT_DEFER_ROOTS
+    uint32_t bq_cap;       // items the queue can hold (rays beyond it are traversed inline)
     uint32_t* counters;    // C_TOTAL
     unsigned long long* stats; // ST_TOTAL, accumulated over the whole render
 };
@@ -119,6 +127,27 @@ RT_FN uint32_t item_path(const RenderArgs& A, const Batch& B, int depth, uint32_
     return depth == 0 ? idx : B.queue[depth & 1][idx];
 }
 
+// Queue a ray whose Mesh gates passed for the compacted BVH kernel; falls back to traversing
+// inline when the queue is full.  `best` is the closest hit among the non-mesh primitives.
+template <bool AO, bool STATS>
+RT_FN bool defer_bvh(const DScene& S, const Batch& B, uint32_t counter, f3 o, f3 d, Hit& best, uint32_t dst,
+                     Stack st, uint32_t sp, Counters& cnt)
+{
+    uint32_t slot = queue_slot(&B.counters[counter]);
+    if (slot >= B.bq_cap) {
+        RayCull rc = make_cull(S, o, d);
+        bvh_drain<STATS, false>(S, o, d, rc, best, st, sp, cnt);
+        return false;
+    }
+    q4 a = {o.x, o.y, o.z, best.t};
+    q4 b = {d.x, d.y, d.z, u2f(dst)};
+    B.bq_a[slot] = a; B.bq_b[slot] = b;
+    if (!AO) { q4 c = {u2f(best.prim), u2f(best.rank), best.u, best.v}; B.bq_c[slot] = c; }
+    for (uint32_t k = 0; k < sp; ++k) B.bq_roots[(size_t)k * B.bq_cap + slot] = st.p[k * st.stride];
+    if (sp < RT_DEFER_ROOTS) B.bq_roots[(size_t)sp * B.bq_cap + slot] = (uint32_t)REF_NONE;
+    return true;
+}
+
 template <bool STATS>
 RT_FN void trace_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, Stack st, Counters& cnt)
 {
@@ -126,9 +155,32 @@ RT_FN void trace_item(const DScene& S, const RenderArgs& A, const Batch& B, int 
     if (depth == 0 && !path_of(A, p).valid) return;
     q4 o4 = B.ray_o[depth & 1][p], d4 = B.ray_d[depth & 1][p];
     Hit h; float sh;
-    trace<0, STATS>(S, xyz(o4), xyz(d4), FLT_MAX, h, sh, st, cnt);
+    uint32_t sp = trace<0, STATS, true>(S, xyz(o4), xyz(d4), FLT_MAX, h, sh, st, cnt);
+    if (sp > 0 && defer_bvh<false, STATS>(S, B, C_BQ + depth, xyz(o4), xyz(d4), h, p, st, sp, cnt)) return;
     q4 r = {h.t, u2f(h.prim), h.u, h.v};
     B.hit[p] = r;
+}
+
+// One item of the compacted BVH kernel: every lane holds a ray that has triangle BVHs to search.
+// AO = 0: closest-hit query, result -> hit[dst];  AO = 1: occlusion distance -> ao_t[dst].
+template <bool AO, bool STATS>
+RT_FN void bvh_item(const DScene& S, const Batch& B, uint32_t idx, Stack st, Counters& cnt)
+{
+    q4 a = B.bq_a[idx], b = B.bq_b[idx];
+    f3 o = xyz(a), d = xyz(b);
+    Hit best; best.t = a.w; best.prim = H_MISS; best.rank = 0; best.u = 0; best.v = 0;
+    if (!AO) { q4 c = B.bq_c[idx]; best.prim = f2u(c.x); best.rank = f2u(c.y); best.u = c.z; best.v = c.w; }
+    RayCull rc = make_cull(S, o, d);
+    for (uint32_t k = 0; k < RT_DEFER_ROOTS; ++k) {
+        uint32_t r = B.bq_roots[(size_t)k * B.bq_cap + idx];
+        if (r == REF_NONE) break;
+        uint32_t sp = 1;
+        st.p[0] = r;
+        bvh_drain<STATS, false>(S, o, d, rc, best, st, sp, cnt);
+    }
+    uint32_t dst = f2u(b.w);
+    if (AO) B.ao_t[dst] = best.t;
+    else { q4 r = {best.t, u2f(best.prim), best.u, best.v}; B.hit[dst] = r; }
 }
 
 RT_FN void prep_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx)
@@ -243,8 +295,10 @@ RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int dep
     f3 o, dir;
     ao_ray(S.ambient, P, N, A.seed, px.key, px.j, a, k, o, dir);
     Hit h; float sh;
-    trace<0, STATS>(S, o, dir, S.ambient.occlusion_dist, h, sh, st, cnt);
-    B.ao_t[(size_t)slot * n2 + k] = h.t;   // stays occlusion_dist when nothing closer was found
+    uint32_t dst = slot * n2 + k;
+    uint32_t sp = trace<0, STATS, true>(S, o, dir, S.ambient.occlusion_dist, h, sh, st, cnt);
+    if (sp > 0 && defer_bvh<true, STATS>(S, B, C_BQA + depth, o, dir, h, dst, st, sp, cnt)) return;
+    B.ao_t[dst] = h.t;   // stays occlusion_dist when nothing closer was found
 }
 
 // world->ambient->L(sr): Light::L, or Ambient::L's reduction of the n*n distances in x,y order
@@ -389,9 +443,11 @@ void render_frame(Backend& be, RenderArgs A, uint32_t owned_tiles, uint32_t tile
         int levels = bounces ? A.levels : 1;
         for (int d = 0; d < levels; ++d) {
             be.trace(A, d, paths);
+            be.bvh_trace(A, d);
             be.prep(A, d, paths);
             be.shadow(A, d);
             be.ao(A, d);
+            be.bvh_ao(A, d);
             be.shade(A, d, paths);
         }
         be.resolve(A, A.npx);

@@ -190,7 +190,7 @@ uint32_t HostScene::add_triangle_slot(uint32_t gid, uint32_t rank)
 namespace {
 struct BuildTri { float mn[3], mx[3], c[3]; uint32_t gid; };
 constexpr uint32_t kLeafMax = 4;
-constexpr int kMaxDepth = 30;   // inner-node depth bound; the kernels keep RT_STACK_DEPTH = 32 entries
+constexpr int kMaxDepth = 24;   // inner-node depth bound: RT_STACK_DEPTH (32) = RT_DEFER_ROOTS (8) pending roots + this
 constexpr int kBins = 16;
 
 inline float half_area(const float* mn, const float* mx)

@@ -5,6 +5,7 @@
 // so the CPU test-suite (-m "not gpu") can check the device arithmetic, the flattened scene and
 // the triangle BVH against the oracle without a GPU.  It is not part of librt_amd.so and the
 // product never loads it.
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -24,6 +25,14 @@ struct LoopBackend {
     void trace(const RenderArgs& A, int d, uint32_t fixed) {
         Stack st{stack.data(), 1};
         for (uint32_t i = 0, n = count(d, fixed); i < n; ++i) trace_item<true>(S, A, B, d, i, st, cnt[0]);
+    }
+    void bvh_trace(const RenderArgs& A, int d) {
+        Stack st{stack.data(), 1};
+        for (uint32_t i = 0, n = std::min(B.counters[C_BQ + d], B.bq_cap); i < n; ++i) bvh_item<false, true>(S, B, i, st, cnt[0]);
+    }
+    void bvh_ao(const RenderArgs& A, int d) {
+        Stack st{stack.data(), 1};
+        for (uint32_t i = 0, n = std::min(B.counters[C_BQA + d], B.bq_cap); i < n; ++i) bvh_item<true, true>(S, B, i, st, cnt[2]);
     }
     void prep(const RenderArgs& A, int d, uint32_t fixed) { for (uint32_t i = 0, n = count(d, fixed); i < n; ++i) prep_item(S, A, B, d, i); }
     void shadow(const RenderArgs& A, int d) {
@@ -105,6 +114,10 @@ int emul_render(const rt_scene_desc* d, const rt_camera* cam, const rt_params* p
     std::vector<float> aot((size_t)P * (n2 ? n2 : 1)), shr((size_t)P * nl), lph((size_t)P * A.levels * (nl > 1 ? nl - 1 : 1));
     std::vector<uint8_t> kind((size_t)P * A.levels);
     std::vector<unsigned long long> stats(ST_TOTAL, 0);
+    // a deliberately small queue so the inline fallback of defer_bvh is exercised too
+    B.bq_cap = P * (n2 ? n2 : 1) / 3 + 1;
+    std::vector<q4> bqa(B.bq_cap), bqb(B.bq_cap), bqc(B.bq_cap); std::vector<uint32_t> bqr((size_t)B.bq_cap * RT_DEFER_ROOTS);
+    B.bq_a = bqa.data(); B.bq_b = bqb.data(); B.bq_c = bqc.data(); B.bq_roots = bqr.data();
     B.ray_o[0] = ro0.data(); B.ray_o[1] = ro1.data(); B.ray_d[0] = rd0.data(); B.ray_d[1] = rd1.data();
     B.hit = hit.data(); B.nrm = nrm.data(); B.pstate = pstate.data(); B.queue[0] = q0.data(); B.queue[1] = q1.data();
     B.ao_queue = aoq.data(); B.ao_slot = aos.data(); B.sh_queue = shq.data(); B.ao_t = aot.data(); B.sh_res = shr.data();
