@@ -18,7 +18,7 @@ def checker_texture(size=128, cells=16, lo=199, hi=231):
     """RGBA8 grey checker equal to the decoded models/teapot/default.png."""
     c = size // cells
     yy, xx = np.mgrid[0:size, 0:size]
-    v = np.where(((xx // c) + (yy // c)) % 2 == 0, hi, lo).astype(np.uint8)
+    v = np.where(((xx // c) + (yy // c)) % 2 == 0, lo, hi).astype(np.uint8)
     rgba = np.stack([v, v, v, np.full_like(v, 255)], axis=-1)
     return S.ImageTexture(rgba)
 
@@ -213,7 +213,7 @@ def config5_scene(width=7680, height=4320, spp=256, instances=2500, mesh_nu=64, 
     mesh_tex = S.Textured(tex)
     obj = torus_objmesh(mesh_tex, mesh_nu, mesh_nv, R=9.0, r=4.0, centre=(0, 0, 0))
     g = int(np.ceil(np.sqrt(instances)))
-    state = np.uint64(seed)
+    state = int(seed)
     bvh = S.BVHAccel()
     count = 0
     for gy in range(g):
@@ -222,8 +222,8 @@ def config5_scene(width=7680, height=4320, spp=256, instances=2500, mesh_nu=64, 
                 break
             vals = []
             for _ in range(3):
-                state = (state * np.uint64(6364136223846793005) + np.uint64(1442695040888963407)) & np.uint64(0xFFFFFFFFFFFFFFFF)
-                vals.append(float((int(state) >> 33) / float(1 << 31)))
+                state = (state * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+                vals.append(float((state >> 33) / float(1 << 31)))
             x = -1000.0 + (gx + 0.25 + 0.5 * vals[0]) * (1300.0 / g)
             z = -420.0 + (gy + 0.25 + 0.5 * vals[1]) * (840.0 / g)
             y = -80.0 + 500.0 * vals[2]

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz by running the REAL reference (oracle/_ref/libref_oracle.so,
+compiled from /root/reference by oracle/Makefile) on the small seeded scenes of tests/util.py.
+
+Each fixture holds inputs-by-name (the scene builders are deterministic code in
+raytracer_amd/scenes.py, the parameters are stored) and the reference's outputs: float32 RGB,
+primary-hit primitive id / t / normal / uv of sample 0, and the closest-hit query count.
+rng_mode 1 = the reference's rand() replaced by the counter hash of include/rt_rng.h and pixel
+sample points drawn from it (see oracle/ref_harness.cpp), which makes jitter + AO reproducible.
+
+Also writes known-answer vectors of single reference functions (kat.npz) and the reference's own
+decode of models/teapot/default.png (teapot_default_rgba.npz).
+Usage:  python tests/golden/make_golden.py        (needs /root/reference; run in the build container)
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import util  # noqa: E402
+from oracle.bindings import RefOracle, f3  # noqa: E402
+from raytracer_amd import capi  # noqa: E402
+
+
+def main():
+    ref = RefOracle()
+    for name, world, params in util.small_scenes():
+        flat = world.flatten()
+        r = ref.render(flat, world.camera, params, rng_mode=1, nthreads=8)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), rgb=r.rgb, primid=r.primid, t=r.t, normal=r.normal,
+                            uv=r.uv, rays=np.uint64(r.rays),
+                            params=np.frombuffer(bytes(params), dtype=np.uint8))
+        print(name, r.rgb.shape, "rays", r.rays)
+
+    # known-answer vectors of single functions
+    rng = np.random.default_rng(1234)
+    L = ref.lib
+    kat = {}
+    ab = rng.uniform(0, 1, (64, 2)).astype(np.float32)
+    hemi = np.zeros((64, 3), np.float32)
+    for i in range(64):
+        out = (C.c_float * 3)()
+        L.ref_sample_hemisphere(float(ab[i, 0]), float(ab[i, 1]), out)
+        hemi[i] = list(out)
+    kat["hemi_in"], kat["hemi_out"] = ab, hemi
+    ups = rng.normal(size=(64, 3)).astype(np.float32)
+    vs = rng.normal(size=(64, 3)).astype(np.float32)
+    rot = np.zeros((64, 3), np.float32)
+    for i in range(64):
+        out = (C.c_float * 3)()
+        L.ref_rotate_to_space(f3(ups[i]), f3(vs[i]), out)
+        rot[i] = list(out)
+    kat["rot_up"], kat["rot_v"], kat["rot_out"] = ups, vs, rot
+    a = rng.uniform(-2, 2, 256).astype(np.float32)
+    b = (a * (1 + rng.choice([0, 1e-8, 6e-8, 1.2e-7, -6e-8, 1e-3], 256))).astype(np.float32)
+    kat["geq_a"], kat["geq_b"] = a, b
+    kat["geq_out"] = np.array([L.ref_geq(float(x), float(y)) for x, y in zip(a, b)], np.int32)
+    cam = capi.rt_camera()
+    cam.eye[:] = [-1000, 300, 250]; cam.look_at[:] = [0, 0, -100]; cam.up[:] = [0, 1, 0]; cam.frustum_dist = 700.0
+    xy = rng.uniform(-500, 500, (64, 2)).astype(np.float32)
+    cd = np.zeros((64, 3), np.float32)
+    for i in range(64):
+        o3, d3 = (C.c_float * 3)(), (C.c_float * 3)()
+        L.ref_camera_ray(C.byref(cam), float(xy[i, 0]), float(xy[i, 1]), o3, d3)
+        cd[i] = list(d3)
+    kat["cam_xy"], kat["cam_d"] = xy, cd
+    # box gate: rays around / inside / grazing a box
+    pts = np.array([[-10, -20, -30], [40, 50, 60], [0, 0, 0], [5, 5, 5], [-10, 50, 0], [40, -20, 60]], np.float32)
+    ro = rng.uniform(-100, 100, (512, 3)).astype(np.float32)
+    rd = rng.normal(size=(512, 3)).astype(np.float32)
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    rd[::7, 0] = 0.0   # axis-parallel components
+    ro[::5] = rng.uniform(-9, 39, (len(ro[::5]), 3)).astype(np.float32)   # origins inside
+    fp = C.POINTER(C.c_float)
+    kat["box_pts"], kat["box_o"], kat["box_d"] = pts, ro, rd
+    kat["box_out"] = np.array([L.ref_box_intersects(pts.ctypes.data_as(fp), 6, f3(ro[i]), f3(rd[i])) for i in range(512)], np.int32)
+    # Phong term
+    n = rng.normal(size=(64, 3)).astype(np.float32); n /= np.linalg.norm(n, axis=1, keepdims=True)
+    wo = rng.normal(size=(64, 3)).astype(np.float32); wo /= np.linalg.norm(wo, axis=1, keepdims=True)
+    wi = rng.normal(size=(64, 3)).astype(np.float32); wi /= np.linalg.norm(wi, axis=1, keepdims=True)
+    kat["spec_n"], kat["spec_wo"], kat["spec_wi"] = n, wo, wi
+    kat["spec_out"] = np.array([L.ref_specular_fn(0.3, 16, f3(n[i]), f3(wo[i]), f3(wi[i])) for i in range(64)], np.float32)
+    # refraction
+    out = np.zeros((64, 4), np.float32)
+    iors = rng.choice([1.0, 1.7], 64).astype(np.float32)
+    for i in range(64):
+        o3 = (C.c_float * 3)(); e = C.c_float()
+        L.ref_refraction(1.7, float(iors[i]), f3(wo[i]), f3(n[i]), o3, C.byref(e))
+        out[i] = list(o3) + [e.value]
+    kat["refr_ior"], kat["refr_out"] = iors, out
+    np.savez_compressed(os.path.join(HERE, "kat.npz"), **kat)
+
+    tex = ref.load_texture("/root/reference/Raytracer/models/teapot/default.png")
+    np.savez_compressed(os.path.join(HERE, "teapot_default_rgba.npz"), rgba=tex)
+    print("texture", tex.shape, np.unique(tex[..., 0]))
+
+
+if __name__ == "__main__":
+    main()

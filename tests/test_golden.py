@@ -1,0 +1,93 @@
+"""The committed golden vectors (tests/golden/*.npz, produced by the REAL reference through
+tests/golden/make_golden.py) against the C oracle and against the host build of the device code."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import util
+from oracle.bindings import f3
+from raytracer_amd import capi, scenes
+
+CASES = util.small_scenes()
+
+
+def load(name):
+    return np.load(os.path.join(util.GOLDEN, name + ".npz"))
+
+
+@pytest.mark.parametrize("name,world,params", CASES, ids=[c[0] for c in CASES])
+def test_oracle_reproduces_reference_fixture(port, name, world, params):
+    g = load(name)
+    assert bytes(g["params"].tobytes()) == bytes(params), "fixture was generated with other parameters"
+    r = port.render(world.flatten(), world.camera, params, rng_mode=1, nthreads=4)
+    assert np.array_equal(r.primid, g["primid"])
+    assert util.bits_equal(r.t, g["t"]) and util.bits_equal(r.normal, g["normal"]) and util.bits_equal(r.uv, g["uv"])
+    assert util.bits_equal(r.rgb, g["rgb"])
+    assert r.rays == int(g["rays"])
+
+
+@pytest.mark.parametrize("name,world,params", CASES, ids=[c[0] for c in CASES])
+def test_device_code_on_host_matches_reference_fixture(emul, name, world, params):
+    """Same arithmetic the GPU runs (rt_core.hpp / rt_pipeline.hpp compiled by g++)."""
+    g = load(name)
+    rgb, prim, t, cnt = emul.render(world.flatten(), world.camera, params)
+    same = prim == g["primid"]
+    assert same.mean() >= 0.9999
+    assert np.array_equal(t[same].view(np.uint32), g["t"][same].view(np.uint32))
+    assert util.lsb_diff(rgb, g["rgb"]).max() <= 1
+    assert (rgb.view(np.uint32) == g["rgb"].view(np.uint32)).mean() >= 0.95
+
+
+def test_known_answer_vectors(port):
+    k = np.load(os.path.join(util.GOLDEN, "kat.npz"))
+    L = port.lib
+    o = (C.c_float * 3)()
+    for i in range(len(k["hemi_in"])):
+        L.oracle_sample_hemisphere(float(k["hemi_in"][i, 0]), float(k["hemi_in"][i, 1]), o)
+        assert np.array_equal(np.array(list(o), np.float32).view(np.uint32), k["hemi_out"][i].view(np.uint32))
+        L.oracle_rotate_to_space(f3(k["rot_up"][i]), f3(k["rot_v"][i]), o)
+        assert np.array_equal(np.array(list(o), np.float32).view(np.uint32), k["rot_out"][i].view(np.uint32))
+    got = [L.oracle_geq(float(a), float(b)) for a, b in zip(k["geq_a"], k["geq_b"])]
+    assert np.array_equal(np.array(got, np.int32), k["geq_out"])
+    cam = capi.rt_camera()
+    cam.eye[:] = [-1000, 300, 250]; cam.look_at[:] = [0, 0, -100]; cam.up[:] = [0, 1, 0]; cam.frustum_dist = 700.0
+    for i in range(len(k["cam_xy"])):
+        o3, d3 = (C.c_float * 3)(), (C.c_float * 3)()
+        L.oracle_camera_ray(C.byref(cam), float(k["cam_xy"][i, 0]), float(k["cam_xy"][i, 1]), o3, d3)
+        assert np.array_equal(np.array(list(d3), np.float32).view(np.uint32), k["cam_d"][i].view(np.uint32))
+    fp = C.POINTER(C.c_float)
+    pts = np.ascontiguousarray(k["box_pts"])
+    got = [L.oracle_box_intersects(pts.ctypes.data_as(fp), 6, f3(k["box_o"][i]), f3(k["box_d"][i])) for i in range(len(k["box_o"]))]
+    assert np.array_equal(np.array(got, np.int32), k["box_out"])
+    assert 0 < k["box_out"].sum() < len(k["box_out"])
+    got = [L.oracle_specular_fn(0.3, 16, f3(k["spec_n"][i]), f3(k["spec_wo"][i]), f3(k["spec_wi"][i])) for i in range(len(k["spec_n"]))]
+    assert np.array_equal(np.array(got, np.float32).view(np.uint32), k["spec_out"].view(np.uint32))
+    for i in range(len(k["refr_ior"])):
+        e = C.c_float()
+        L.oracle_refraction(1.7, float(k["refr_ior"][i]), f3(k["spec_wo"][i]), f3(k["spec_n"][i]), o, C.byref(e))
+        got = np.array(list(o) + [e.value], np.float32)
+        assert np.array_equal(got.view(np.uint32), k["refr_out"][i].view(np.uint32))
+
+
+def test_camera_basis_known_answer(port):
+    """ray through the centre of pixel (r=0,c=0) of the default 1000x1000 camera."""
+    cam = capi.rt_camera()
+    cam.eye[:] = [-1000, 300, 250]; cam.look_at[:] = [0, 0, -100]; cam.up[:] = [0, 1, 0]; cam.frustum_dist = 700.0
+    o3, d3 = (C.c_float * 3)(), (C.c_float * 3)()
+    port.lib.oracle_camera_ray(C.byref(cam), -500.0 + 0.5, -500.0 + 0.5, o3, d3)
+    assert np.allclose(list(d3), [0.934316635, 0.291499883, 0.205134675], rtol=0, atol=2e-7)
+
+
+def test_checker_texture_is_the_reference_decode():
+    g = np.load(os.path.join(util.GOLDEN, "teapot_default_rgba.npz"))["rgba"]
+    assert np.array_equal(g, scenes.checker_texture().rgba)
+
+
+def test_quantize_truncates(port):
+    x = np.array([0.0, 0.999, 1.0, 0.5, 0.00392, 0.00393], np.float32)
+    out = np.zeros(6, np.uint8)
+    port.lib.oracle_quantize(x.ctypes.data, 6, out.ctypes.data)
+    assert list(out) == [0, 254, 255, 127, 0, 1]
+    assert np.array_equal(util.quantize(x), out)
