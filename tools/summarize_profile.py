@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output that tools/profile_round.sh left under gpurun_out/ into the
+tracked summaries under profiles/:  <tag>_kernel_stats.csv (the --stats table), <tag>_pmc.csv
+(per-kernel counter sums and per-launch averages) and profiles/traffic.json (HBM bytes per launch of
+the dominant kernel, corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE is in KiB and, on
+gfx950, reports half of the bytes of wide coalesced reads — the per-lane 16-byte node/triangle
+gathers here are NOT that pattern, so both the raw and the doubled figure are recorded)."""
+import glob
+import json
+import os
+import sys
+
+import pandas as pd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+os.makedirs(P, exist_ok=True)
+
+
+def short(name):
+    import re
+    m = re.search(r"(k_\w+<[\w, ]+>|k_\w+)", name)
+    return m.group(1) if m else name[:40]
+
+
+st = glob.glob(os.path.join(G, f"{tag}_stats", "*", "*_kernel_stats.csv"))
+if st:
+    df = pd.read_csv(st[0])
+    df["Name"] = df["Name"].map(short)
+    df.to_csv(os.path.join(P, f"{tag}_kernel_stats.csv"), index=False)
+    print(df[["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"]].to_string(index=False))
+    log = os.path.join(G, f"{tag}_stats.log")
+    if os.path.exists(log):
+        lines = [l for l in open(log) if l.startswith("{")]
+        if lines:
+            open(os.path.join(P, f"{tag}_bench_under_rocprof.json"), "w").write(lines[-1])
+
+rows = []
+for sub in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
+    f = glob.glob(os.path.join(G, f"{tag}_{sub}", "*", "*_counter_collection.csv"))
+    if not f:
+        continue
+    df = pd.read_csv(f[0])
+    df["k"] = df["Kernel_Name"].map(short)
+    g = df.groupby(["k", "Counter_Name"])["Counter_Value"].agg(["sum", "count"]).reset_index()
+    rows.append(g)
+if rows:
+    allc = pd.concat(rows)
+    allc["per_launch"] = allc["sum"] / allc["count"]
+    allc = allc[allc["k"].str.startswith("k_")]
+    allc.to_csv(os.path.join(P, f"{tag}_pmc.csv"), index=False)
+    piv = allc.pivot_table(index="k", columns="Counter_Name", values="per_launch")
+    print(piv.to_string())
+    k = "k_bvh<true, false>"
+    if k in piv.index and "FETCH_SIZE" in piv.columns:
+        fetch_kib = float(piv.loc[k, "FETCH_SIZE"])
+        write_kib = float(piv.loc[k, "WRITE_SIZE"]) if "WRITE_SIZE" in piv.columns else 0.0
+        out = {
+            "kernel": k, "tag": tag,
+            "fetch_bytes_per_launch_raw": fetch_kib * 1024, "write_bytes_per_launch": write_kib * 1024,
+            "k_bvh_ao_bytes_per_launch": fetch_kib * 1024 + write_kib * 1024,
+            "k_bvh_ao_bytes_per_launch_if_fetch_doubled": 2 * fetch_kib * 1024 + write_kib * 1024,
+            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB -> bytes, averaged over the "
+                    "launches of one frame (steps 1, warmup 1); raw FETCH_SIZE used (scattered 16-B gathers, not the "
+                    "wide coalesced stream for which gfx950 under-reports by 2x)",
+        }
+        json.dump(out, open(os.path.join(P, "traffic.json"), "w"), indent=1)
+        print(json.dumps(out, indent=1))
