@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--mesh-nu", type=int, default=700)
     ap.add_argument("--mesh-nv", type=int, default=360)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (RCCL over xGMI) or gloo (rehearsal: ranks may share one GPU, slabs staged through the host)")
     ap.add_argument("--cpu-crop", type=int, default=32, help="edge of the centre crop timed on the CPU")
     args = ap.parse_args()
 
@@ -39,6 +40,7 @@ def main():
     import torch
     import torch.distributed as dist
     from raytracer_amd import capi, scenes
+    from raytracer_amd import dist as rdist
     from raytracer_amd.render import Renderer
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -48,15 +50,19 @@ def main():
         if world_size == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     distributed = world_size > 1
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    gpu_index = local_rank % max(1, torch.cuda.device_count()) if args.backend == "gloo" else local_rank
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
     if distributed:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     world = scenes.config3_scene(args.width, args.height, args.spp, args.mesh_nu, args.mesh_nv)
     flat = world.flatten()
     ntri = int(flat.arrays["triangles"].shape[0])
-    r = Renderer(local_rank)
+    r = Renderer(gpu_index)
     r.upload(flat)
     params = world.params(seed=1)
     params.tile_rank, params.tile_world = rank, world_size
@@ -67,21 +73,25 @@ def main():
     if distributed:
         slab = torch.zeros((max_owned, capi.RT_TILE * capi.RT_TILE, 3), dtype=torch.float32, device=dev)
         out = slab
-        gather_list = [torch.zeros_like(slab) for _ in range(world_size)] if rank == 0 else None
+        gather_list = [torch.zeros_like(slab) for _ in range(world_size)] if rank == 0 and args.backend == "nccl" else None
         frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev) if rank == 0 else None
     else:
         frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
         out = frame
 
+    def unpack(src, t):
+        # on torch's current stream: ordered behind the gather that filled `t`
+        r.unpack_tiles(t.data_ptr(), params, src, world_size, frame.data_ptr(), torch.cuda.current_stream().cuda_stream)
+
     def step(flags=0, stats=None):
         params.flags = flags
         # stream=None: the library's own stream, and the call returns when the frame is complete
         r.render_device(world.camera, params, out.data_ptr(), None, None, stats, None)
-        if distributed:
-            dist.gather(slab, gather_list, dst=0)
-            if rank == 0:
-                for src in range(world_size):
-                    r.unpack_tiles(gather_list[src].data_ptr(), params, src, world_size, frame.data_ptr(), None)
+        if distributed:   # the one exchange step: slabs -> rank 0 over RCCL, scattered into the frame there
+            if args.backend == "nccl":
+                rdist.gather_frame(slab, params, rank, world_size, unpack, gather_list=gather_list)
+            else:
+                rdist.gather_frame(slab.cpu(), params, rank, world_size, lambda src, t: unpack(src, t.to(dev)))
 
     def sync():
         torch.cuda.synchronize()
@@ -147,12 +157,14 @@ def main():
             "mrays_per_s_in_kernel": round(units / (k_ms * 1e-3) / 1e6, 1) if k_ms > 0 else None,
             "ao_rays_total": int(ao_rays), "ao_rays_needing_bvh": int(units),
         }
+        torch.cuda.synchronize()
+        checksum = int(frame.view(torch.int32).to(torch.int64).sum().item()) & 0xFFFFFFFFFFFFFFFF   # same for every N
         line = {
             "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world_size,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"config3: {W}x{H}, {args.spp} jittered spp + 4x4 ambient occlusion, room + textured "
-                                   f"{ntri}-triangle BVH mesh, 1 point light", "rays_per_frame": int(rays_total),
+                                   f"{ntri}-triangle BVH mesh, 1 point light", "rays_per_frame": int(rays_total), "frame_checksum": checksum,
                        "parallelism": f"tiles64 x {world_size} gpu"},
             "kernel_ms_per_step": {n: round(float(kernel_ms[i]) / args.steps, 3) for i, n in enumerate(capi.RT_K_NAMES)},
             "roofline": roofline,

@@ -767,14 +767,26 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* p, float* rgb,
         HIPCHECK(ctx, hipMalloc((void**)&ctx->d_t, npix * 4));
         ctx->out_pixels = npix;
     }
-    const bool partial = p->x0 != 0 || p->y0 != 0 || p->x1 != p->width || p->y1 != p->height || p->tile_world > 1;
-    if (partial) {   // keep what the caller has outside the rendered pixels
+    const bool rect = p->x0 != 0 || p->y0 != 0 || p->x1 != p->width || p->y1 != p->height;
+    const bool split = p->tile_world > 1;
+    if (split) {   // keep what the caller has in the pixels other ranks own
         if (rgb) HIPCHECK(ctx, hipMemcpyAsync(ctx->d_rgb, rgb, npix * 12, hipMemcpyHostToDevice, ctx->stream));
         if (primid) HIPCHECK(ctx, hipMemcpyAsync(ctx->d_prim, primid, npix * 4, hipMemcpyHostToDevice, ctx->stream));
         if (t) HIPCHECK(ctx, hipMemcpyAsync(ctx->d_t, t, npix * 4, hipMemcpyHostToDevice, ctx->stream));
     }
     rc = render_locked(s, cam, p, ctx->d_rgb, primid ? ctx->d_prim : nullptr, t ? ctx->d_t : nullptr, stats, ctx->stream, false, true);
     if (rc) return rc;
+    if (rect && !split) {
+        // raytrace(beginY,endY,beginX,endX): only the rectangle travels back, pixels outside it stay the caller's
+        const size_t w = (size_t)(p->x1 - p->x0), h = (size_t)(p->y1 - p->y0), W = (size_t)p->width;
+        const size_t first = (size_t)p->y0 * W + (size_t)p->x0;
+        if (w && h) {
+            if (rgb) HIPCHECK(ctx, hipMemcpy2D(rgb + first * 3, W * 12, ctx->d_rgb + first * 3, W * 12, w * 12, h, hipMemcpyDeviceToHost));
+            if (primid) HIPCHECK(ctx, hipMemcpy2D(primid + first, W * 4, ctx->d_prim + first, W * 4, w * 4, h, hipMemcpyDeviceToHost));
+            if (t) HIPCHECK(ctx, hipMemcpy2D(t + first, W * 4, ctx->d_t + first, W * 4, w * 4, h, hipMemcpyDeviceToHost));
+        }
+        return RT_OK;
+    }
     if (rgb) HIPCHECK(ctx, hipMemcpy(rgb, ctx->d_rgb, npix * 12, hipMemcpyDeviceToHost));
     if (primid) HIPCHECK(ctx, hipMemcpy(primid, ctx->d_prim, npix * 4, hipMemcpyDeviceToHost));
     if (t) HIPCHECK(ctx, hipMemcpy(t, ctx->d_t, npix * 4, hipMemcpyDeviceToHost));

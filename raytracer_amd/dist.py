@@ -56,7 +56,7 @@ def unpack_slab_numpy(slab, params, rank, world, frame):
     return frame
 
 
-def gather_frame(slab, params, rank, world, unpack, group=None):
+def gather_frame(slab, params, rank, world, unpack, group=None, gather_list=None):
     """Collective: every rank passes its slab (torch tensor [max_owned, TILE*TILE, 3]); rank 0 gets
     them all (dist.gather = grouped send/recv: 7 concurrent point-to-point transfers on xGMI) and
     calls unpack(src_rank, slab_tensor) for each.  Returns True on rank 0."""
@@ -65,7 +65,8 @@ def gather_frame(slab, params, rank, world, unpack, group=None):
     if world == 1:
         unpack(0, slab)
         return True
-    gather_list = [torch.empty_like(slab) for _ in range(world)] if rank == 0 else None
+    if gather_list is None and rank == 0:
+        gather_list = [torch.empty_like(slab) for _ in range(world)]
     dist.gather(slab, gather_list, dst=0, group=group)
     if rank == 0:
         for src in range(world):

@@ -1,0 +1,334 @@
+// raytracer_amd/host/Raytracer.cpp — implementation of the C++ host mirror: scene flattening into
+// the arrays of include/rt_amd.h, the render calls, the thread pool, the BMP writer and the small
+// OBJ / PPM / TGA readers.  Links against librt_amd.so only.
+#include "Raytracer.hpp"
+
+#include <algorithm>
+
+namespace {
+
+[[noreturn]] void fail(const std::string& what, rt_ctx* ctx = nullptr)
+{
+    throw std::runtime_error(what + ": " + rt_last_error(ctx));
+}
+
+// ---- flattening World -> rt_scene_desc arrays -----------------------------------------------------
+struct Flat {
+    std::vector<rt_plane> planes; std::vector<rt_sphere> spheres; std::vector<rt_triangle> triangles;
+    std::vector<rt_mesh> meshes; std::vector<rt_multimesh> multimeshes; std::vector<rt_bvh> bvhs;
+    std::vector<rt_shape_ref> leaves, scene; std::vector<rt_material> materials; std::vector<rt_texture> textures;
+    std::vector<rt_light> lights; rt_ambient ambient{};
+    std::map<const Material*, int> mat_ids; std::map<const ImageTexture*, int> tex_ids; std::map<const Shape*, rt_shape_ref> seen;
+
+    int tex_id(const std::shared_ptr<ImageTexture>& t)
+    {
+        if (!t) return -1;
+        auto it = tex_ids.find(t.get());
+        if (it != tex_ids.end()) return it->second;
+        int id = (int)textures.size();
+        textures.push_back(rt_texture{t->mWidth, t->mHeight, t->mSet ? t->mImage.data() : nullptr});
+        return tex_ids[t.get()] = id;
+    }
+    int mat_id(const std::shared_ptr<Material>& m)
+    {
+        if (!m) throw std::runtime_error("shape without a material");
+        auto it = mat_ids.find(m.get());
+        if (it != mat_ids.end()) return it->second;
+        rt_material c = m->c;
+        c.texture = tex_id(m->texture);
+        int id = (int)materials.size();
+        materials.push_back(c);
+        return mat_ids[m.get()] = id;
+    }
+    uint32_t add_mesh(const Mesh& m)
+    {
+        uint32_t first = (uint32_t)triangles.size();
+        int mat = mat_id(m.mMaterial);
+        for (rt_triangle t : m.mTriangles) { t.material = mat; triangles.push_back(t); }
+        meshes.push_back(rt_mesh{first, (uint32_t)m.mTriangles.size()});
+        return (uint32_t)meshes.size() - 1;
+    }
+    rt_shape_ref ref_of(const std::shared_ptr<Shape>& s)
+    {
+        auto it = seen.find(s.get());
+        if (it != seen.end()) return it->second;
+        rt_shape_ref r{};
+        if (auto p = dynamic_cast<Plane*>(s.get())) {
+            planes.push_back(rt_plane{{p->mPoint.x, p->mPoint.y, p->mPoint.z}, {p->mNormal.x, p->mNormal.y, p->mNormal.z}, mat_id(p->mMaterial)});
+            r = {RT_SHAPE_PLANE, (uint32_t)planes.size() - 1};
+        } else if (auto sp = dynamic_cast<Sphere*>(s.get())) {
+            spheres.push_back(rt_sphere{{sp->mCentre.x, sp->mCentre.y, sp->mCentre.z}, sp->mRadius, mat_id(sp->mMaterial)});
+            r = {RT_SHAPE_SPHERE, (uint32_t)spheres.size() - 1};
+        } else if (auto t = dynamic_cast<Triangle*>(s.get())) {
+            rt_triangle c{{t->mV0.x, t->mV0.y, t->mV0.z}, {t->mV1.x, t->mV1.y, t->mV1.z}, {t->mV2.x, t->mV2.y, t->mV2.z},
+                          {t->mUV0.x, t->mUV0.y}, {t->mUV1.x, t->mUV1.y}, {t->mUV2.x, t->mUV2.y}, mat_id(t->mMaterial)};
+            triangles.push_back(c);
+            r = {RT_SHAPE_TRIANGLE, (uint32_t)triangles.size() - 1};
+        } else if (auto me = dynamic_cast<Mesh*>(s.get())) {
+            r = {RT_SHAPE_MESH, add_mesh(*me)};
+        } else if (auto mm = dynamic_cast<MultiMesh*>(s.get())) {
+            uint32_t first = (uint32_t)meshes.size();
+            for (auto& m : mm->meshes) add_mesh(m);
+            multimeshes.push_back(rt_multimesh{first, (uint32_t)mm->meshes.size()});
+            r = {RT_SHAPE_MULTIMESH, (uint32_t)multimeshes.size() - 1};
+        } else if (auto b = dynamic_cast<BVHAccel*>(s.get())) {
+            std::vector<rt_shape_ref> mine;
+            for (auto& l : b->mLeaves) mine.push_back(ref_of(l));
+            bvhs.push_back(rt_bvh{(uint32_t)leaves.size(), (uint32_t)mine.size()});
+            leaves.insert(leaves.end(), mine.begin(), mine.end());
+            r = {RT_SHAPE_BVH, (uint32_t)bvhs.size() - 1};
+        } else {
+            throw std::runtime_error("unknown Shape subclass");
+        }
+        return seen[s.get()] = r;
+    }
+};
+
+struct Gpu {   // one context + the uploaded scene of the World last rendered
+    rt_ctx* ctx = nullptr; rt_scene* scene = nullptr;
+    const World* world = nullptr; unsigned long revision = ~0ul;
+    std::mutex mu;
+    ~Gpu() { if (scene) rt_scene_destroy(scene); if (ctx) rt_shutdown(ctx); }
+};
+Gpu& gpu() { static Gpu g; return g; }
+
+void ensure_uploaded(Gpu& g, const World& w)
+{
+    if (!g.ctx && rt_init(0, &g.ctx) != RT_OK) fail("rt_init");
+    if (g.world == &w && g.revision == w.mRevision && g.scene) return;
+    if (g.scene) { rt_scene_destroy(g.scene); g.scene = nullptr; }
+    Flat f;
+    for (auto& s : w.scene) f.scene.push_back(f.ref_of(s));
+    for (auto& l : w.lights) f.lights.push_back(rt_light{l->mKind, {l->mV.x, l->mV.y, l->mV.z}, {l->mColour.x, l->mColour.y, l->mColour.z}, l->mRadiance});
+    if (w.ambient) f.ambient = rt_ambient{{w.ambient->mColour.x, w.ambient->mColour.y, w.ambient->mColour.z}, w.ambient->mRadiance,
+                                          w.ambient->mOcclusionSamples, w.ambient->mOcclusionRayDist};
+    rt_scene_desc d{};
+    d.planes = f.planes.data(); d.num_planes = (uint32_t)f.planes.size();
+    d.spheres = f.spheres.data(); d.num_spheres = (uint32_t)f.spheres.size();
+    d.triangles = f.triangles.data(); d.num_triangles = (uint32_t)f.triangles.size();
+    d.meshes = f.meshes.data(); d.num_meshes = (uint32_t)f.meshes.size();
+    d.multimeshes = f.multimeshes.data(); d.num_multimeshes = (uint32_t)f.multimeshes.size();
+    d.bvhs = f.bvhs.data(); d.num_bvhs = (uint32_t)f.bvhs.size();
+    d.bvh_leaves = f.leaves.data(); d.num_bvh_leaves = (uint32_t)f.leaves.size();
+    d.scene = f.scene.data(); d.num_scene = (uint32_t)f.scene.size();
+    d.materials = f.materials.data(); d.num_materials = (uint32_t)f.materials.size();
+    d.textures = f.textures.data(); d.num_textures = (uint32_t)f.textures.size();
+    d.lights = f.lights.data(); d.num_lights = (uint32_t)f.lights.size();
+    d.ambient = f.ambient;
+    if (rt_scene_create(g.ctx, &g.scene) != RT_OK) fail("rt_scene_create", g.ctx);
+    if (rt_scene_set_desc(g.scene, &d) != RT_OK) fail("rt_scene_set_desc", g.ctx);
+    if (rt_scene_commit(g.scene) != RT_OK) fail("rt_scene_commit", g.ctx);
+    g.world = &w; g.revision = w.mRevision;
+}
+
+void render_rect(int y0, int y1, int x0, int x1, Camera const& camera, std::shared_ptr<World> const& world, rt_stats* stats)
+{
+    Gpu& g = gpu();
+    std::lock_guard<std::mutex> lk(g.mu);   // pool threads calling raytrace() concurrently serialise here
+    ensure_uploaded(g, *world);
+    if (world->image.size() != world->width * world->height) world->image.assign(world->width * world->height, Colour{0, 0, 0});
+    rt_params p;
+    rt_params_default(&p);
+    p.width = (int)world->width; p.height = (int)world->height;
+    p.x0 = x0; p.x1 = x1; p.y0 = y0; p.y1 = y1;
+    if (world->sampler) { p.num_samples = world->sampler->mNumSamples; p.num_sets = world->sampler->mNumSets; p.sampler = world->sampler->mKind; }
+    p.max_depth = world->maxDepth; p.light_attenuation = (float)lightAttenuationFactor; p.seed = world->seed;
+    if (stats) p.flags = RT_FLAG_TIMING;
+    static_assert(sizeof(Colour) == 3 * sizeof(float), "Colour must be three packed floats");
+    rt_camera cam = camera.toC();
+    if (rt_render(g.scene, &cam, &p, reinterpret_cast<float*>(world->image.data()), nullptr, nullptr, stats) != RT_OK) fail("rt_render", g.ctx);
+}
+
+} // namespace
+
+void raytrace(int beginBlockY, int endBlockY, int beginBlockX, int endBlockX, Camera const& camera, std::shared_ptr<World> const& world)
+{
+    render_rect(beginBlockY, endBlockY, beginBlockX, endBlockX, camera, world, nullptr);
+}
+
+void render(Camera const& camera, std::shared_ptr<World> const& world, rt_stats* stats)
+{
+    render_rect(0, (int)world->height, 0, (int)world->width, camera, world, stats);
+}
+
+// ---- meshes ----------------------------------------------------------------------------------------
+Mesh::Mesh(atlas::utils::Shape const& shape, unsigned int matIndex, std::vector<std::shared_ptr<Textured>> const& loadedMaterials,
+           std::string, Vector offset)
+{
+    if (shape.indices.size() % 3 != 0) return;
+    for (size_t k = 0; k + 2 < shape.indices.size(); k += 3) {
+        rt_triangle t{};
+        const atlas::utils::Vertex* v[3] = {&shape.vertices[shape.indices[k]], &shape.vertices[shape.indices[k + 1]], &shape.vertices[shape.indices[k + 2]]};
+        float* pos[3] = {t.v0, t.v1, t.v2}; float* uv[3] = {t.uv0, t.uv1, t.uv2};
+        for (int c = 0; c < 3; ++c) {
+            pos[c][0] = v[c]->position.x + offset.x; pos[c][1] = v[c]->position.y + offset.y; pos[c][2] = v[c]->position.z + offset.z;
+            uv[c][0] = v[c]->texCoord.x; uv[c][1] = v[c]->texCoord.y;
+        }
+        mTriangles.push_back(t);
+    }
+    if (!shape.materialIds.empty()) {   // reference main.cpp:868-872 (indexed by shape index)
+        int id = shape.materialIds[std::min<size_t>(matIndex, shape.materialIds.size() - 1)];
+        if (id >= 0 && (size_t)id < loadedMaterials.size()) mMaterial = loadedMaterials[id];
+    }
+}
+
+MultiMesh::MultiMesh(atlas::utils::ObjMesh const& mesh, std::string modelSubDirName, Vector offset)
+{
+    std::vector<std::shared_ptr<Textured>> loaded;
+    for (auto& m : mesh.materials) loaded.push_back(std::make_shared<Textured>(m, modelSubDirName));
+    for (unsigned int i = 0; i < mesh.shapes.size(); ++i) meshes.push_back(Mesh(mesh.shapes[i], i, loaded, modelSubDirName, offset));
+}
+
+// ---- thread pool (reference main.cpp:80-143; completion uses a counter + predicate) ----------------------
+ThreadPool::ThreadPool(unsigned int const& numThreads)
+{
+    for (unsigned i = 0; i < std::max(1u, numThreads); ++i) mThreads.emplace_back(&ThreadPool::loopFunction, this);
+}
+void ThreadPool::loopFunction()
+{
+    for (;;) {
+        std::function<void()> job;
+        {
+            std::unique_lock<std::mutex> lock(mQueueMutex);
+            mCondition.wait(lock, [&] { return !mQueue.empty() || mTerminatePool; });
+            if (mTerminatePool && mQueue.empty()) return;
+            job = std::move(mQueue.front());
+            mQueue.pop();
+        }
+        job();
+        {
+            std::unique_lock<std::mutex> lock(mQueueMutex);
+            if (--mPending == 0) mComplCondition.notify_all();
+        }
+    }
+}
+void ThreadPool::startJob(std::function<void()> job)
+{
+    {
+        std::unique_lock<std::mutex> lock(mQueueMutex);
+        mQueue.push(std::move(job));
+        ++mPending;
+    }
+    mCondition.notify_one();
+}
+void ThreadPool::waitDone()
+{
+    std::unique_lock<std::mutex> lock(mQueueMutex);
+    mComplCondition.wait(lock, [&] { return mPending == 0; });
+}
+ThreadPool::~ThreadPool()
+{
+    {
+        std::unique_lock<std::mutex> lock(mQueueMutex);
+        mTerminatePool = true;
+    }
+    mCondition.notify_all();
+    for (auto& t : mThreads) t.join();
+}
+
+// ---- saveToFile (reference main.cpp:1837-1857 + stbi_write_bmp's file layout) ------------------------------
+void saveToFile(std::string const& filename, std::size_t width, std::size_t height, std::vector<Colour> const& image)
+{
+    const size_t pad = (4 - (width * 3) % 4) % 4, row = width * 3 + pad;
+    std::vector<unsigned char> out(54 + row * height, 0);
+    auto put32 = [&](size_t o, uint32_t v) { out[o] = v & 255; out[o + 1] = (v >> 8) & 255; out[o + 2] = (v >> 16) & 255; out[o + 3] = (v >> 24) & 255; };
+    out[0] = 'B'; out[1] = 'M';
+    put32(2, (uint32_t)out.size()); put32(10, 54); put32(14, 40); put32(18, (uint32_t)width); put32(22, (uint32_t)height);
+    out[26] = 1; out[28] = 24;
+    for (size_t r = 0; r < height; ++r)
+        for (size_t c = 0; c < width; ++c) {
+            const Colour& p = image[r * width + c];
+            unsigned char* o = &out[54 + (height - 1 - r) * row + c * 3];
+            o[2] = static_cast<unsigned char>(p.r * 255); o[1] = static_cast<unsigned char>(p.g * 255); o[0] = static_cast<unsigned char>(p.b * 255);
+        }
+    std::ofstream f(filename, std::ios::binary);
+    f.write(reinterpret_cast<const char*>(out.data()), (std::streamsize)out.size());
+}
+
+// ---- small readers -------------------------------------------------------------------------------------
+ImageTexture::ImageTexture(std::string const& path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return;
+    std::vector<unsigned char> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (d.size() > 2 && d[0] == 'P' && d[1] == '6') {
+        std::istringstream hs(std::string(d.begin(), d.begin() + std::min<size_t>(d.size(), 64)));
+        std::string magic; int w = 0, h = 0, mx = 0;
+        hs >> magic >> w >> h >> mx;
+        size_t off = (size_t)hs.tellg() + 1;
+        if (w <= 0 || h <= 0 || mx != 255 || d.size() < off + (size_t)w * h * 3) return;
+        mImage.resize((size_t)w * h * 4);
+        for (size_t i = 0; i < (size_t)w * h; ++i) { mImage[i * 4] = d[off + i * 3]; mImage[i * 4 + 1] = d[off + i * 3 + 1]; mImage[i * 4 + 2] = d[off + i * 3 + 2]; mImage[i * 4 + 3] = 255; }
+        mWidth = w; mHeight = h; mSet = true;
+    } else if (d.size() > 18 && d[2] == 2 && (d[16] == 24 || d[16] == 32)) {   // uncompressed true-colour TGA
+        int w = d[12] | (d[13] << 8), h = d[14] | (d[15] << 8), bpp = d[16] / 8;
+        size_t off = 18 + d[0];
+        if (w <= 0 || h <= 0 || d.size() < off + (size_t)w * h * bpp) return;
+        bool top = (d[17] & 0x20) != 0;
+        mImage.resize((size_t)w * h * 4);
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                const unsigned char* s = &d[off + ((size_t)(top ? y : h - 1 - y) * w + x) * bpp];
+                unsigned char* o = &mImage[((size_t)y * w + x) * 4];
+                o[0] = s[2]; o[1] = s[1]; o[2] = s[0]; o[3] = bpp == 4 ? s[3] : 255;
+            }
+        mWidth = w; mHeight = h; mSet = true;
+    }
+}
+
+std::optional<atlas::utils::ObjMesh> atlas::utils::loadObjMesh(std::string const& filename, std::string const& materialPath)
+{
+    std::ifstream f(filename);
+    if (!f) return std::nullopt;
+    std::string dir = materialPath.empty() ? filename.substr(0, filename.find_last_of("/\\") + 1) : materialPath;
+    ObjMesh out;
+    std::vector<math::Point> pos; std::vector<math::Point2> tex;
+    std::map<std::string, int> mat_index;
+    int cur_mat = -1;
+    auto shape = [&]() -> Shape& { if (out.shapes.empty()) out.shapes.emplace_back(); return out.shapes.back(); };
+    std::string line;
+    while (std::getline(f, line)) {
+        std::istringstream ls(line);
+        std::string tag;
+        if (!(ls >> tag)) continue;
+        if (tag == "v") { math::Point p; ls >> p.x >> p.y >> p.z; pos.push_back(p); }
+        else if (tag == "vt") { math::Point2 t; ls >> t.x >> t.y; tex.push_back(t); }
+        else if (tag == "o" || tag == "g") { if (out.shapes.empty() || !out.shapes.back().indices.empty()) out.shapes.emplace_back(); }
+        else if (tag == "mtllib") {
+            std::string name; ls >> name;
+            std::ifstream m(dir + name);
+            std::string ml;
+            while (std::getline(m, ml)) {
+                std::istringstream ms(ml);
+                std::string t2;
+                if (!(ms >> t2)) continue;
+                if (t2 == "newmtl") { tinyobj::material_t mt; ms >> mt.name; mat_index[mt.name] = (int)out.materials.size(); out.materials.push_back(mt); }
+                else if (t2 == "map_Kd" && !out.materials.empty()) { ms >> out.materials.back().diffuse_texname; std::replace(out.materials.back().diffuse_texname.begin(), out.materials.back().diffuse_texname.end(), '\\', '/'); }
+            }
+        } else if (tag == "usemtl") { std::string name; ls >> name; auto it = mat_index.find(name); cur_mat = it == mat_index.end() ? -1 : it->second; }
+        else if (tag == "f") {
+            Shape& s = shape();
+            std::vector<std::size_t> face;
+            std::string vtx;
+            while (ls >> vtx) {
+                int vi = 0, ti = 0;
+                std::sscanf(vtx.c_str(), "%d/%d", &vi, &ti);
+                Vertex v;
+                if (vi < 0) vi = (int)pos.size() + vi + 1;
+                if (ti < 0) ti = (int)tex.size() + ti + 1;
+                if (vi >= 1 && (size_t)vi <= pos.size()) v.position = pos[vi - 1];
+                if (ti >= 1 && (size_t)ti <= tex.size()) v.texCoord = tex[ti - 1];
+                v.index = s.vertices.size();
+                s.vertices.push_back(v);
+                face.push_back(v.index);
+            }
+            for (size_t k = 1; k + 1 < face.size(); ++k) {   // fan-triangulate
+                s.indices.push_back(face[0]); s.indices.push_back(face[k]); s.indices.push_back(face[k + 1]);
+                s.materialIds.push_back(cur_mat);
+            }
+        }
+    }
+    // the reference reads materialIds[shape index]: make every entry of a shape its material
+    for (auto& s : out.shapes) if (!s.materialIds.empty()) { int m = s.materialIds[0]; s.materialIds.assign(std::max(s.materialIds.size(), out.shapes.size()), m); }
+    return out;
+}
