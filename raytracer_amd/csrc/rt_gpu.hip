@@ -84,8 +84,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B
     const uint32_t n = B.counters[C_AO + depth] * n2;
     Stack st{s_stack + threadIdx.x, RT_BLOCK};
     Counters cnt{0, 0, 0};
-    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK)
-        ao_item<STATS>(S, A, B, depth, i, st, cnt);
+    QCursor qc{0, 0};
+    // wave-uniform trip count: every lane of a wave takes part in the queue cursor's ballots
+    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        ao_item<STATS>(S, A, B, depth, i, i < n, st, cnt, qc);
+    }
+    close_cursor(B, qc);
     flush_counters<STATS>(cnt, B.stats, 2);
 }
 
@@ -123,6 +128,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
     uint32_t sp = 0, cur = REF_NONE, dst = 0, npend = 0, tri_next = 0, tri_left = 0;
     bool active = false, exhausted = false;
     uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform
+    uint32_t nrays = 0;
     for (;;) {
         // ---- retire finished rays -------------------------------------------------------------
         if (active && cur == REF_NONE && npend == 0 && tri_left == 0) {
@@ -157,7 +163,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
                         if (r == REF_NONE) break;
                         stk[(sp++) * RT_BLOCK] = r;
                     }
-                    if (sp > 0) { cur = stk[(--sp) * RT_BLOCK]; active = true; }   // a slot without roots is a hole
+                    if (sp > 0) { cur = stk[(--sp) * RT_BLOCK]; active = true; if (STATS) nrays++; }   // a slot without roots is a hole
                 }
             }
         }
@@ -223,6 +229,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
         }
     }
     flush_counters<STATS>(cnt, B.stats, AO ? 2 : 0);
+    if (STATS) {
+        for (int off = 32; off > 0; off >>= 1) nrays += __shfl_xor(nrays, off);
+        if (lane == 0) atomicAdd(&B.stats[ST_BVHRAYS + (AO ? 2 : 0)], (unsigned long long)nrays);
+    }
 }
 
 __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
@@ -236,16 +246,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_resolve(DScene S, RenderArgs A, Ba
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) resolve_item(S, A, B, i);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const unsigned n2 = (unsigned)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
-        unsigned long long sh = 0, ao = 0, bo = 0, bt = 0, ba = 0;
+        unsigned long long sh = 0, ao = 0, bo = 0;
         for (int d = 0; d < levels_run; ++d) {
-            bt += B.counters[C_BQ + d] < B.bq_cap ? B.counters[C_BQ + d] : B.bq_cap;
-            ba += B.counters[C_BQA + d] < B.bq_cap ? B.counters[C_BQA + d] : B.bq_cap;
             sh += B.counters[C_SH + d];
             ao += (unsigned long long)B.counters[C_AO + d] * n2;
             if (d > 0) bo += B.counters[C_QUEUE + d];
         }
         B.stats[ST_SHADOW] += sh; B.stats[ST_AO] += ao; B.stats[ST_BOUNCE] += bo;
-        B.stats[ST_BVHRAYS + 0] += bt; B.stats[ST_BVHRAYS + 2] += ba;
     }
 }
 
@@ -412,6 +419,10 @@ size_t carve_batch(Batch& B, char* base, uint32_t P, int levels, uint32_t nl, ui
     B.lvl_ph = (float*)take(4ull * P * levels * (nl > 1 ? nl - 1 : 1));
     B.lvl_kind = (uint8_t*)take((size_t)P * levels);
     B.bq_cap = P * (n2 ? n2 : 1);
+    if (n2) {   // room for the holes k_ao's chunked appends leave: one open chunk per wave + chunk tails
+        const size_t rays = (size_t)P * n2, waves = std::min<size_t>((size_t)RT_MAX_GRID * (RT_BLOCK / 64), (rays + 63) / 64);
+        B.bq_cap = (uint32_t)std::min<size_t>(rays + waves * RT_QCHUNK + rays / 16, 0xFFFF0000u);
+    }
     B.bq_a = (q4*)take(sizeof(q4) * (size_t)B.bq_cap);
     B.bq_b = (q4*)take(sizeof(q4) * (size_t)B.bq_cap);
     B.bq_c = (q4*)take(sizeof(q4) * (size_t)P);

@@ -148,6 +148,62 @@ RT_FN bool defer_bvh(const DScene& S, const Batch& B, uint32_t counter, f3 o, f3
     return true;
 }
 
+// AO flavour of defer_bvh for the GPU's hottest append (one per AO ray that meets a Mesh).  A single
+// counter word serves only ~90 returning atomics per microsecond, so a wave reserves RT_QCHUNK
+// consecutive slots with ONE atomic and hands them out by ballot + prefix sum from a wave-uniform
+// cursor.  Slots a wave reserves but never fills (the tail of a chunk) are marked as holes (no
+// roots); k_bvh skips them.  Must be called by all 64 lanes of the wave (`want` selects).
+struct QCursor { uint32_t next, end; };
+#define RT_QCHUNK 1024u
+
+template <bool STATS>
+RT_FN bool defer_ao(const DScene& S, const Batch& B, uint32_t counter, bool want, f3 o, f3 d, Hit& best, uint32_t dst,
+                    Stack st, uint32_t sp, Counters& cnt, QCursor& qc)
+{
+    uint32_t slot = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long mask = __ballot(want);
+    const uint32_t nw = (uint32_t)__popcll(mask);
+    if (nw == 0) return false;
+    const uint32_t lane = __lane_id();
+    if (qc.next + nw > qc.end) {
+        const uint32_t rem = qc.end - qc.next;   // < 64
+        if (lane < rem && qc.next + lane < B.bq_cap) B.bq_roots[qc.next + lane] = (uint32_t)REF_NONE;
+        uint32_t b0 = 0;
+        if (lane == 0) b0 = atomicAdd(&B.counters[counter], RT_QCHUNK);
+        b0 = __shfl(b0, 0);
+        qc.next = b0; qc.end = b0 + RT_QCHUNK;
+    }
+    slot = qc.next + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    qc.next += nw;
+#else
+    (void)qc;
+    if (want) slot = B.counters[counter]++;
+#endif
+    if (!want) return false;
+    if (slot >= B.bq_cap) {
+        RayCull rc = make_cull(S, o, d);
+        bvh_drain<STATS, false>(S, o, d, rc, best, st, sp, cnt);
+        return false;
+    }
+    q4 a = {o.x, o.y, o.z, best.t};
+    q4 b = {d.x, d.y, d.z, u2f(dst)};
+    B.bq_a[slot] = a; B.bq_b[slot] = b;
+    for (uint32_t k = 0; k < sp; ++k) B.bq_roots[(size_t)k * B.bq_cap + slot] = st.p[k * st.stride];
+    if (sp < RT_DEFER_ROOTS) B.bq_roots[(size_t)sp * B.bq_cap + slot] = (uint32_t)REF_NONE;
+    return true;
+}
+
+// marks the unused rest of the wave's last chunk as holes (GPU; all lanes of the wave)
+RT_FN void close_cursor(const Batch& B, const QCursor& qc)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (uint32_t s = qc.next + __lane_id(); s < qc.end && s < B.bq_cap; s += 64u) B.bq_roots[s] = (uint32_t)REF_NONE;
+#else
+    (void)B; (void)qc;
+#endif
+}
+
 template <bool STATS>
 RT_FN void trace_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, Stack st, Counters& cnt)
 {
@@ -279,26 +335,30 @@ RT_FN void shadow_item(const DScene& S, const RenderArgs& A, const Batch& B, int
 }
 
 template <bool STATS>
-RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, Stack st, Counters& cnt)
+RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, bool valid, Stack st,
+                   Counters& cnt, QCursor& qc)
 {
     // stratum-major order: a wave traces the same stratum (x,y) of 64 neighbouring hits, whose
     // rays leave nearby points in similar directions, instead of the 16 directions of 4 hits
-    uint32_t nslots = B.counters[C_AO + depth];
-    uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
-    uint32_t slot = idx % nslots, k = idx / nslots;
-    uint32_t p = B.ao_queue[slot];
-    PathPix px = path_of(A, p);
-    q4 o4 = B.ray_o[depth & 1][p], d4 = B.ray_d[depth & 1][p];
-    f3 P = xyz(o4) + xyz(d4) * B.hit[p].x;
-    f3 N = xyz(B.nrm[p]);
-    uint32_t a = (B.pstate[p] >> 8) & 0xFFu;
-    f3 o, dir;
-    ao_ray(S.ambient, P, N, A.seed, px.key, px.j, a, k, o, dir);
-    Hit h; float sh;
-    uint32_t dst = slot * n2 + k;
-    uint32_t sp = trace<0, STATS, true>(S, o, dir, S.ambient.occlusion_dist, h, sh, st, cnt);
-    if (sp > 0 && defer_bvh<true, STATS>(S, B, C_BQA + depth, o, dir, h, dst, st, sp, cnt)) return;
-    B.ao_t[dst] = h.t;   // stays occlusion_dist when nothing closer was found
+    f3 o = F3(0, 0, 0), dir = F3(0, 0, 1);
+    Hit h = {}; float sh;
+    uint32_t dst = 0, sp = 0;
+    if (valid) {
+        uint32_t nslots = B.counters[C_AO + depth];
+        uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
+        uint32_t slot = idx % nslots, k = idx / nslots;
+        uint32_t p = B.ao_queue[slot];
+        PathPix px = path_of(A, p);
+        q4 o4 = B.ray_o[depth & 1][p], d4 = B.ray_d[depth & 1][p];
+        f3 P = xyz(o4) + xyz(d4) * B.hit[p].x;
+        f3 N = xyz(B.nrm[p]);
+        uint32_t a = (B.pstate[p] >> 8) & 0xFFu;
+        ao_ray(S.ambient, P, N, A.seed, px.key, px.j, a, k, o, dir);
+        dst = slot * n2 + k;
+        sp = trace<0, STATS, true>(S, o, dir, S.ambient.occlusion_dist, h, sh, st, cnt);
+    }
+    if (defer_ao<STATS>(S, B, C_BQA + depth, sp > 0, o, dir, h, dst, st, sp, cnt, qc)) return;
+    if (valid) B.ao_t[dst] = h.t;   // stays occlusion_dist when nothing closer was found
 }
 
 // world->ambient->L(sr): Light::L, or Ambient::L's reduction of the n*n distances in x,y order

@@ -42,7 +42,8 @@ struct LoopBackend {
     void ao(const RenderArgs& A, int d) {
         Stack st{stack.data(), 1};
         uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
-        for (uint32_t i = 0, n = B.counters[C_AO + d] * n2; i < n; ++i) ao_item<true>(S, A, B, d, i, st, cnt[2]);
+        QCursor qc{0, 0};
+        for (uint32_t i = 0, n = B.counters[C_AO + d] * n2; i < n; ++i) ao_item<true>(S, A, B, d, i, true, st, cnt[2], qc);
     }
     void shade(const RenderArgs& A, int d, uint32_t fixed) { for (uint32_t i = 0, n = count(d, fixed); i < n; ++i) shade_item(S, A, B, d, i); }
     void resolve(const RenderArgs& A, uint32_t n) {
