@@ -110,15 +110,28 @@ __global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B
 #define RT_BVH_CHUNK 512
 #define RT_REFILL_IDLE 16    // refill once this many lanes hold no ray
 #define RT_PEND 4            // parked leaves per lane
+#define RT_LDS_STACK 12      // stack entries per lane kept in LDS; deeper ones spill to global memory (rare)
+
 template <bool AO, bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter, int next_counter)
 {
-    __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_BLOCK];
+    __shared__ uint32_t s_stack[RT_LDS_STACK * RT_BLOCK];
     __shared__ uint32_t s_pend[RT_PEND * RT_BLOCK];
+    uint32_t* const spill = B.bq_spill + (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    const size_t spill_stride = (size_t)RT_MAX_GRID * RT_BLOCK;
+    auto push = [&](uint32_t& sp_, uint32_t x) {
+        if (sp_ < RT_LDS_STACK) s_stack[sp_ * RT_BLOCK + threadIdx.x] = x;
+        else if (sp_ < RT_STACK_DEPTH) spill[(size_t)(sp_ - RT_LDS_STACK) * spill_stride] = x;
+        else return;
+        ++sp_;
+    };
+    auto pop = [&](uint32_t& sp_) -> uint32_t {
+        --sp_;
+        return sp_ < RT_LDS_STACK ? s_stack[sp_ * RT_BLOCK + threadIdx.x] : spill[(size_t)(sp_ - RT_LDS_STACK) * spill_stride];
+    };
     uint32_t n = B.counters[counter];
     if (n > B.bq_cap) n = B.bq_cap;
     uint32_t* next = &B.counters[next_counter];
-    uint32_t* stk = s_stack + threadIdx.x;
     uint32_t* pend = s_pend + threadIdx.x;
     Counters cnt{0, 0, 0};
     const uint32_t lane = threadIdx.x & 63u;
@@ -161,9 +174,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
                     for (uint32_t k = 0; k < RT_DEFER_ROOTS; ++k) {
                         const uint32_t r = B.bq_roots[(size_t)k * B.bq_cap + idx];
                         if (r == REF_NONE) break;
-                        stk[(sp++) * RT_BLOCK] = r;
+                        push(sp, r);
                     }
-                    if (sp > 0) { cur = stk[(--sp) * RT_BLOCK]; active = true; if (STATS) nrays++; }   // a slot without roots is a hole
+                    if (sp > 0) { cur = pop(sp); active = true; if (STATS) nrays++; }   // a slot without roots is a hole
                 }
             }
         }
@@ -178,28 +191,31 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
         }
         if (n_node > n_tri) {
             if (can_node) {
-                if (cur & REF_LEAF) {
-                    pend[(npend++) * RT_BLOCK] = cur;
-                    cur = sp == 0 ? (uint32_t)REF_NONE : stk[(--sp) * RT_BLOCK];
-                } else {
-                    const q4* nd = S.nodes + (size_t)cur * 4;
-                    const q4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+                uint32_t c0 = REF_NONE, c1 = REF_NONE;
+                if (!(cur & REF_LEAF)) {
+                    const q4* np = S.nodes + (size_t)cur * 4;
+                    const q4 nd[4] = {np[0], np[1], np[2], np[3]};
                     if (STATS) cnt.nodes++;
-                    const uint32_t r0 = f2u(n3.x), r1 = f2u(n3.y);
+                    const uint32_t r0 = f2u(nd[3].x), r1 = f2u(nd[3].y);
                     float t0, t1;
-                    const bool h0 = r0 != REF_NONE && cull_box(rc, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, best.t, t0);
-                    const bool h1 = r1 != REF_NONE && cull_box(rc, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, best.t, t1);
-                    if (h0 && h1) {
-                        const bool swap = t1 < t0;
-                        if (sp < RT_STACK_DEPTH) stk[(sp++) * RT_BLOCK] = swap ? r0 : r1;
-                        cur = swap ? r1 : r0;
-                    } else if (h0) {
-                        cur = r0;
-                    } else if (h1) {
-                        cur = r1;
-                    } else {
-                        cur = sp == 0 ? (uint32_t)REF_NONE : stk[(--sp) * RT_BLOCK];
-                    }
+                    const bool h0 = r0 != REF_NONE && cull_box(rc, nd[0].x, nd[0].y, nd[0].z, nd[0].w, nd[1].x, nd[1].y, best.t, t0);
+                    const bool h1 = r1 != REF_NONE && cull_box(rc, nd[1].z, nd[1].w, nd[2].x, nd[2].y, nd[2].z, nd[2].w, best.t, t1);
+                    const bool swap = h0 && h1 && t1 < t0;
+                    c0 = h0 ? r0 : (uint32_t)REF_NONE; c1 = h1 ? r1 : (uint32_t)REF_NONE;
+                    if (swap) { const uint32_t x = c0; c0 = c1; c1 = x; }
+                } else {
+                    c0 = cur;   // a leaf that arrived as a root or waited for room
+                }
+                // leaves are parked for the triangle steps; inner nodes continue the descent
+                if (c0 != REF_NONE && (c0 & REF_LEAF) && npend < RT_PEND) { pend[(npend++) * RT_BLOCK] = c0; c0 = REF_NONE; }
+                if (c1 != REF_NONE && (c1 & REF_LEAF) && npend < RT_PEND) { pend[(npend++) * RT_BLOCK] = c1; c1 = REF_NONE; }
+                if (c0 == REF_NONE) { c0 = c1; c1 = REF_NONE; }
+                if (c1 != REF_NONE) push(sp, c1);
+                cur = c0;
+                while (cur == REF_NONE && sp > 0) {   // pop; leaves that come off the stack are parked right away
+                    const uint32_t x = pop(sp);
+                    if ((x & REF_LEAF) && npend < RT_PEND) pend[(npend++) * RT_BLOCK] = x;
+                    else cur = x;
                 }
             }
         } else {
@@ -427,6 +443,7 @@ size_t carve_batch(Batch& B, char* base, uint32_t P, int levels, uint32_t nl, ui
     B.bq_b = (q4*)take(sizeof(q4) * (size_t)B.bq_cap);
     B.bq_c = (q4*)take(sizeof(q4) * (size_t)P);
     B.bq_roots = (uint32_t*)take(4ull * RT_DEFER_ROOTS * (size_t)B.bq_cap);
+    B.bq_spill = (uint32_t*)take(4ull * (RT_STACK_DEPTH - RT_LDS_STACK) * RT_MAX_GRID * RT_BLOCK);
     return off;
 }
 } // namespace

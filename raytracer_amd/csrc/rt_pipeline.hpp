@@ -46,6 +46,7 @@ struct Batch {
     q4* bq_c;              // closest-hit queries only: {bits(prim), bits(rank), u, v} of that closest hit
     uint32_t* bq_roots;    // [k * bq_cap + item]: mesh-BVH roots, terminated by REF_NONE when fewer than RT_DEFER_ROOTS
     uint32_t bq_cap;       // items the queue can hold (rays beyond it are traversed inline)
+    uint32_t* bq_spill;    // GPU: k_bvh's stack entries beyond its short LDS stack, [entry][global lane]
     uint32_t* counters;    // C_TOTAL
     unsigned long long* stats; // ST_TOTAL, accumulated over the whole render
 };
