@@ -76,7 +76,8 @@ struct DScene {
     const q4* spheres;   // 2 / sphere: {centre, radius} {radius^2, bits(material), 0, 0}
     const q4* tris;      // 3 / slot  : {v0, bits(global tri)} {e1=v1-v0, bits(material)} {e2=v2-v0, bits(rank = reference visiting order)}
     const q4* tri_attr;  // 2 / global triangle: {uv0, uv1} {uv2, 0, 0}
-    const q4* nodes;     // 4 / BVH2 node (64 B): both child boxes + child refs
+    const q4* nodes;     // 2 / BVH2 node (32 B): both child boxes as 12 x 16-bit grid indices + 2 child refs
+    f3 qbase, qscale;    // node grid: coordinate = qbase + q * qscale (one frame per scene)
     const DMaterial* materials;
     const DLight* lights; uint32_t num_lights;
     const DTexture* textures; const uint8_t* texels; uint32_t num_textures;
@@ -190,8 +191,10 @@ RT_FN bool closer(float t, uint32_t rank, const Hit& h) { return t < h.t || (t =
 // interval (-inf, best.t): children are culled with a slab test padded by
 // pad = cull_pad * (|o|_inf + extent) so that float rounding in the reference's Moller-Trumbore
 // arithmetic can never accept a triangle whose box was culled.  Culling never decides a hit.
-struct RayCull { float ix, iy, iz, lx, ly, lz, hx, hy, hz; };
+struct RayCull { float sx, sy, sz, lx, ly, lz, hx, hy, hz; };
 
+// Node boxes are 16-bit grid indices q (coordinate = qbase + q*qscale, rounded outwards by the
+// builder), so the slab distances are affine in q: t = q * (qscale/d) + (qbase - o -+ pad)/d.
 RT_FN RayCull make_cull(const DScene& S, f3 o, f3 d)
 {
     RayCull c;
@@ -199,25 +202,39 @@ RT_FN RayCull make_cull(const DScene& S, f3 o, f3 d)
     float dx = fabsf(d.x) > 1e-20f ? d.x : (d.x < 0 ? -1e-20f : 1e-20f);
     float dy = fabsf(d.y) > 1e-20f ? d.y : (d.y < 0 ? -1e-20f : 1e-20f);
     float dz = fabsf(d.z) > 1e-20f ? d.z : (d.z < 0 ? -1e-20f : 1e-20f);
-    c.ix = 1.0f / dx; c.iy = 1.0f / dy; c.iz = 1.0f / dz;
-    c.lx = -(o.x + pad) * c.ix; c.hx = -(o.x - pad) * c.ix;
-    c.ly = -(o.y + pad) * c.iy; c.hy = -(o.y - pad) * c.iy;
-    c.lz = -(o.z + pad) * c.iz; c.hz = -(o.z - pad) * c.iz;
+    float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    float bx = S.qbase.x - o.x, by = S.qbase.y - o.y, bz = S.qbase.z - o.z;
+    c.sx = S.qscale.x * ix; c.sy = S.qscale.y * iy; c.sz = S.qscale.z * iz;
+    c.lx = (bx - pad) * ix; c.hx = (bx + pad) * ix;
+    c.ly = (by - pad) * iy; c.hy = (by + pad) * iy;
+    c.lz = (bz - pad) * iz; c.hz = (bz + pad) * iz;
     return c;
 }
+
+RT_FN float q_lo(float w) { return (float)(f2u(w) & 0xFFFFu); }
+RT_FN float q_hi(float w) { return (float)(f2u(w) >> 16); }
 
 RT_FN bool cull_box(const RayCull& c, float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
                     float tbest, float& tnear)
 {
-    float ax = fmaf(mnx, c.ix, c.lx), bx = fmaf(mxx, c.ix, c.hx);
-    float ay = fmaf(mny, c.iy, c.ly), by = fmaf(mxy, c.iy, c.hy);
-    float az = fmaf(mnz, c.iz, c.lz), bz = fmaf(mxz, c.iz, c.hz);
+    float ax = fmaf(mnx, c.sx, c.lx), bx = fmaf(mxx, c.sx, c.hx);
+    float ay = fmaf(mny, c.sy, c.ly), by = fmaf(mxy, c.sy, c.hy);
+    float az = fmaf(mnz, c.sz, c.lz), bz = fmaf(mxz, c.sz, c.hz);
     float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     float f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     tnear = n;
     // widen by a relative slack for the rounding of the slab arithmetic itself
     float slack = 4e-6f * fmaxf(fabsf(n), fabsf(f));
     return (n - slack <= f + slack) && (n - slack <= tbest);
+}
+
+// both child boxes of a 32-byte node {w0..w3}{w4,w5,ref0,ref1}: w = lo | hi<<16 over the sequence
+// lo0.x lo0.y lo0.z hi0.x hi0.y hi0.z lo1.x ... hi1.z
+RT_FN void node_test(const RayCull& rc, q4 n0, q4 n1, float tbest, bool& h0, bool& h1, float& t0, float& t1, uint32_t& r0, uint32_t& r1)
+{
+    r0 = f2u(n1.z); r1 = f2u(n1.w);
+    h0 = cull_box(rc, q_lo(n0.x), q_hi(n0.x), q_lo(n0.y), q_hi(n0.y), q_lo(n0.z), q_hi(n0.z), tbest, t0) && r0 != REF_NONE;
+    h1 = cull_box(rc, q_lo(n0.w), q_hi(n0.w), q_lo(n1.x), q_hi(n1.x), q_lo(n1.y), q_hi(n1.y), tbest, t1) && r1 != REF_NONE;
 }
 
 template <bool STATS, bool ANYHIT>
@@ -234,13 +251,13 @@ RT_FN bool bvh_drain(const DScene& S, f3 o, f3 d, const RayCull& rc, Hit& best, 
     uint32_t cur = st.p[(--sp) * st.stride];
     while (cur != REF_NONE) {
         while (!(cur & REF_LEAF)) {   // cur is an inner node (REF_NONE has bit 31 clear but never gets here: see pops)
-            const q4* n = S.nodes + (size_t)cur * 4;
-            q4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            const q4* n = S.nodes + (size_t)cur * 2;
+            q4 n0 = n[0], n1 = n[1];
             if (STATS) cnt.nodes++;
-            uint32_t r0 = f2u(n3.x), r1 = f2u(n3.y);
+            uint32_t r0, r1;
             float t0, t1;
-            bool h0 = r0 != REF_NONE && cull_box(rc, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, best.t, t0);
-            bool h1 = r1 != REF_NONE && cull_box(rc, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, best.t, t1);
+            bool h0, h1;
+            node_test(rc, n0, n1, best.t, h0, h1, t0, t1, r0, r1);
             if (h0 && h1) {
                 bool swap = t1 < t0;
                 uint32_t nearc = swap ? r1 : r0, farc = swap ? r0 : r1;

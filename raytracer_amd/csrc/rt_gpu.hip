@@ -193,13 +193,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
             if (can_node) {
                 uint32_t c0 = REF_NONE, c1 = REF_NONE;
                 if (!(cur & REF_LEAF)) {
-                    const q4* np = S.nodes + (size_t)cur * 4;
-                    const q4 nd[4] = {np[0], np[1], np[2], np[3]};
+                    const q4* np = S.nodes + (size_t)cur * 2;
+                    const q4 n0 = np[0], n1 = np[1];
                     if (STATS) cnt.nodes++;
-                    const uint32_t r0 = f2u(nd[3].x), r1 = f2u(nd[3].y);
+                    uint32_t r0, r1;
                     float t0, t1;
-                    const bool h0 = r0 != REF_NONE && cull_box(rc, nd[0].x, nd[0].y, nd[0].z, nd[0].w, nd[1].x, nd[1].y, best.t, t0);
-                    const bool h1 = r1 != REF_NONE && cull_box(rc, nd[1].z, nd[1].w, nd[2].x, nd[2].y, nd[2].z, nd[2].w, best.t, t1);
+                    bool h0, h1;
+                    node_test(rc, n0, n1, best.t, h0, h1, t0, t1, r0, r1);
                     const bool swap = h0 && h1 && t1 < t0;
                     c0 = h0 ? r0 : (uint32_t)REF_NONE; c1 = h1 ? r1 : (uint32_t)REF_NONE;
                     if (swap) { const uint32_t x = c0; c0 = c1; c1 = x; }
@@ -632,6 +632,7 @@ int rt_scene_commit(rt_scene* s)
     D.prim_base_tri = (uint32_t)(H.planes.size() + H.spheres.size());
     D.cull_pad = 1.0f / 262144.0f;
     D.extent = H.extent;
+    D.qbase = F3(H.qbase[0], H.qbase[1], H.qbase[2]); D.qscale = F3(H.qscale[0], H.qscale[1], H.qscale[2]);
     D.debug = getenv("RT_DEBUG") ? (uint32_t)atoi(getenv("RT_DEBUG")) : 0u;
     s->committed = true;
     return RT_OK;

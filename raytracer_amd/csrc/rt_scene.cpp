@@ -186,7 +186,8 @@ uint32_t HostScene::add_triangle_slot(uint32_t gid, uint32_t rank)
     return slot;
 }
 
-// ---- triangle BVH of one Mesh: binned SAH, <= 4 triangles per leaf, 64-byte two-child nodes ----
+// ---- triangle BVH of one Mesh: binned SAH, <= 4 triangles per leaf, two-child nodes (built as 64-byte
+//      float nodes, shipped as 32-byte quantised nodes: quantize_nodes) ----
 namespace {
 struct BuildTri { float mn[3], mx[3], c[3]; uint32_t gid; };
 constexpr uint32_t kLeafMax = 4;
@@ -230,7 +231,7 @@ uint32_t HostScene::mesh_bvh(uint32_t mesh, uint32_t rank_base)
         return REF_LEAF | ((hi - lo - 1u) << 28) | first;
     };
     uint32_t max_depth_seen = 0;
-    // returns the child reference for T[lo,hi); inner nodes are appended to nodes4
+    // returns the child reference for T[lo,hi); inner nodes are appended to fnodes4
     std::function<uint32_t(uint32_t, uint32_t, int)> build = [&](uint32_t lo, uint32_t hi, int depth) -> uint32_t {
         const uint32_t n = hi - lo;
         if (n <= kLeafMax) return make_leaf(lo, hi);
@@ -291,34 +292,80 @@ uint32_t HostScene::mesh_bvh(uint32_t mesh, uint32_t rank_base)
             std::nth_element(T.begin() + lo, T.begin() + mid, T.begin() + hi,
                              [&](const BuildTri& x, const BuildTri& y) { return x.c[a] < y.c[a]; });
         }
-        const size_t me = nodes4.size() / 4;
-        nodes4.resize(nodes4.size() + 4);
+        const size_t me = fnodes4.size() / 4;
+        fnodes4.resize(fnodes4.size() + 4);
         float lmn[3], lmx[3], rmn[3], rmx[3];
         bounds(lo, mid, lmn, lmx); bounds(mid, hi, rmn, rmx);
         uint32_t l = build(lo, mid, depth + 1);
         uint32_t r = build(mid, hi, depth + 1);
-        nodes4[me * 4 + 0] = {lmn[0], lmn[1], lmn[2], lmx[0]};
-        nodes4[me * 4 + 1] = {lmx[1], lmx[2], rmn[0], rmn[1]};
-        nodes4[me * 4 + 2] = {rmn[2], rmx[0], rmx[1], rmx[2]};
-        nodes4[me * 4 + 3] = {u2f(l), u2f(r), 0.0f, 0.0f};
+        fnodes4[me * 4 + 0] = {lmn[0], lmn[1], lmn[2], lmx[0]};
+        fnodes4[me * 4 + 1] = {lmx[1], lmx[2], rmn[0], rmn[1]};
+        fnodes4[me * 4 + 2] = {rmn[2], rmx[0], rmx[1], rmx[2]};
+        fnodes4[me * 4 + 3] = {u2f(l), u2f(r), 0.0f, 0.0f};
         return (uint32_t)me;
     };
     uint32_t root;
     if (m.num_triangles <= kLeafMax) {
         float mn[3], mx[3];
         bounds(0, m.num_triangles, mn, mx);
-        root = (uint32_t)(nodes4.size() / 4);
+        root = (uint32_t)(fnodes4.size() / 4);
         uint32_t leaf = make_leaf(0, m.num_triangles);
-        nodes4.push_back({mn[0], mn[1], mn[2], mx[0]});
-        nodes4.push_back({mx[1], mx[2], INFINITY, INFINITY});
-        nodes4.push_back({INFINITY, -INFINITY, -INFINITY, -INFINITY});
-        nodes4.push_back({u2f(leaf), u2f((uint32_t)REF_NONE), 0.0f, 0.0f});
+        fnodes4.push_back({mn[0], mn[1], mn[2], mx[0]});
+        fnodes4.push_back({mx[1], mx[2], INFINITY, INFINITY});
+        fnodes4.push_back({INFINITY, -INFINITY, -INFINITY, -INFINITY});
+        fnodes4.push_back({u2f(leaf), u2f((uint32_t)REF_NONE), 0.0f, 0.0f});
     } else {
         root = build(0, m.num_triangles, 0);
     }
     bvh_max_depth = std::max(bvh_max_depth, max_depth_seen);
     mesh_root_[mesh] = root; mesh_rank_[mesh] = rank_base;
     return root;
+}
+
+// 64-byte float nodes -> 32-byte nodes: the 12 box coordinates become 16-bit grid indices in ONE frame
+// for the whole scene (qbase + q * qscale), rounded outwards by a full grid step beyond floor/ceil, so
+// the decoded box always contains the float box (checked below with the decode arithmetic of
+// cull_box's callers); the traversal's padded slab test then works on a superset, which culling allows.
+void HostScene::quantize_nodes()
+{
+    const size_t n = fnodes4.size() / 4;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    auto box_of = [&](size_t i, int child, float* lo, float* hi) {
+        const float* f = &fnodes4[i * 4].x;
+        for (int a = 0; a < 3; ++a) { lo[a] = f[child * 6 + a]; hi[a] = f[child * 6 + 3 + a]; }
+    };
+    for (size_t i = 0; i < n; ++i)
+        for (int c = 0; c < 2; ++c) {
+            if (f2u((&fnodes4[i * 4 + 3].x)[c]) == REF_NONE) continue;
+            float lo[3], hi[3]; box_of(i, c, lo, hi);
+            for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], lo[a]); mx[a] = std::max(mx[a], hi[a]); }
+        }
+    for (int a = 0; a < 3; ++a) {
+        if (!(mn[a] <= mx[a])) { mn[a] = 0.0f; mx[a] = 1.0f; }
+        qbase[a] = mn[a];
+        qscale[a] = std::max((mx[a] - mn[a]) / 65533.0f, 1e-30f);
+    }
+    nodes4.assign(n * 2, q4{0, 0, 0, 0});
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t q[12] = {0};
+        for (int c = 0; c < 2; ++c) {
+            if (f2u((&fnodes4[i * 4 + 3].x)[c]) == REF_NONE) continue;
+            float lo[3], hi[3]; box_of(i, c, lo, hi);
+            for (int a = 0; a < 3; ++a) {
+                double l = std::floor(((double)lo[a] - (double)qbase[a]) / (double)qscale[a]) - 1.0;
+                double h = std::ceil(((double)hi[a] - (double)qbase[a]) / (double)qscale[a]) + 1.0;
+                uint32_t ql = (uint32_t)std::min(65535.0, std::max(0.0, l)), qh = (uint32_t)std::min(65535.0, std::max(0.0, h));
+                // the decode the kernels' arithmetic implies: base + q*scale in float
+                while (ql > 0 && qbase[a] + (float)ql * qscale[a] > lo[a]) --ql;
+                while (qh < 65535 && qbase[a] + (float)qh * qscale[a] < hi[a]) ++qh;
+                q[c * 6 + a] = ql; q[c * 6 + 3 + a] = qh;
+            }
+        }
+        uint32_t w[6];
+        for (int k = 0; k < 6; ++k) w[k] = q[2 * k] | (q[2 * k + 1] << 16);
+        nodes4[i * 2 + 0] = {u2f(w[0]), u2f(w[1]), u2f(w[2]), u2f(w[3])};
+        nodes4[i * 2 + 1] = {u2f(w[4]), u2f(w[5]), fnodes4[i * 4 + 3].x, fnodes4[i * 4 + 3].y};
+    }
 }
 
 void HostScene::emit_mesh(uint32_t mesh, uint32_t item, uint32_t rank_base)
@@ -414,7 +461,7 @@ int HostScene::build()
     error.clear();
     int rc = validate();
     if (rc) return rc;
-    gates.clear(); planes4.clear(); spheres4.clear(); tris4.clear(); attr4.clear(); nodes4.clear();
+    gates.clear(); planes4.clear(); spheres4.clear(); tris4.clear(); attr4.clear(); nodes4.clear(); fnodes4.clear();
     dmaterials.clear(); dlights.clear(); dtextures.clear(); texels.clear(); item_opaque.clear();
     bvh_max_depth = 0;
 
@@ -466,6 +513,7 @@ int HostScene::build()
     }
     if (item_opaque.empty()) item_opaque.push_back(1);
     if (bvh_max_depth > (uint32_t)kMaxDepth + 1) { error = "triangle BVH deeper than the traversal stack"; return RT_ERR_UNSUPPORTED; }
+    quantize_nodes();
 
     has_bounce_materials = false;
     for (auto& m : materials) {

@@ -33,6 +33,8 @@ struct HostScene {
     // ---- flattened form (what gets uploaded) ----
     std::vector<GateNode> gates;
     std::vector<q4> planes4, spheres4, tris4, attr4, nodes4;
+    std::vector<q4> fnodes4;            // build-time float nodes (4 q4 each); nodes4 holds the quantised 2-q4 nodes
+    float qbase[3] = {0, 0, 0}, qscale[3] = {1, 1, 1};   // node grid: coordinate = qbase + q * qscale
     std::vector<DMaterial> dmaterials;
     std::vector<DLight> dlights;
     std::vector<DTexture> dtextures;
@@ -57,6 +59,7 @@ private:
     int shape_box(const rt_shape_ref& r, Aabb& out);
     uint32_t prim_count(const rt_shape_ref& r);
     uint32_t mesh_bvh(uint32_t mesh, uint32_t rank_base);
+    void quantize_nodes();
     void emit_shape(const rt_shape_ref& r, uint32_t item, uint32_t rank_base);
     void emit_mesh(uint32_t mesh, uint32_t item, uint32_t rank_base);
     int emit_bvh(uint32_t bvh, uint32_t item, uint32_t rank_base);
