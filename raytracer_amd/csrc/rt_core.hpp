@@ -49,11 +49,14 @@ RT_FN float clampf(float x, float lo, float hi) { float m = (x < lo) ? lo : x; r
 RT_FN f3 clamp01(f3 L) { return F3(clampf(L.x, 0.0f, 1.0f), clampf(L.y, 0.0f, 1.0f), clampf(L.z, 0.0f, 1.0f)); }
 
 // ---- flattened scene (built by rt_scene.cpp, resident in HBM) -------------------------------
-enum : uint32_t { G_GROUP = 0, G_GATED = 1, G_PLANE = 2, G_SPHERE = 3, G_TRI = 4, G_MESH = 5 };
+enum : uint32_t { G_GROUP = 0, G_GATED = 1, G_PLANE = 2, G_SPHERE = 3, G_TRI = 4, G_MESH = 5, G_KIND_MASK = 0xFFu,
+                  G_SAME_BOX = 0x100u };   // flag: box bit-identical to the enclosing gate's, whose test already passed
 
 // Shape-level structure of the reference, in depth-first preorder with skip pointers (no stack):
 // world->scene entries, BVHAccel internal nodes, MultiMesh and Mesh gates.  A gated node is
 // entered only if the reference's own box test passes (BoundingVolumeBox::intersects).
+// PLANE and SPHERE nodes carry their primitive inline (no second fetch during the walk):
+// PLANE: mn = point, mx = normal; SPHERE: mn = centre, mx = {radius^2, radius, 0}.
 struct alignas(16) GateNode {
     float mn[3]; uint32_t kind;
     float mx[3]; uint32_t skip;  // next node when this subtree is not entered
@@ -72,6 +75,7 @@ struct DTexture { uint32_t offset; int32_t width, height; int32_t set; };
 
 struct DScene {
     const GateNode* gates; uint32_t num_gates;
+    const GateNode* gates_fast; uint32_t num_gates_fast;   // GPU: the first nodes staged in LDS by the kernel (0 = none)
     const q4* planes;    // 2 / plane : {point, bits(material)} {normal, 0}
     const q4* spheres;   // 2 / sphere: {centre, radius} {radius^2, bits(material), 0, 0}
     const q4* tris;      // 3 / slot  : {v0, bits(global tri)} {e1=v1-v0, bits(material)} {e2=v2-v0, bits(rank = reference visiting order)}
@@ -119,6 +123,44 @@ RT_FN bool plane_t(f3 point, f3 normal, f3 o, f3 d, float& t)
     float tt = dot(point - o, normal) / denom;
     if (tt >= 0 && tt < FLT_MAX) { t = tt; return true; }
     return false;
+}
+
+// Conservative pre-test for the reference's box gate below.  The exact test can only pass when the
+// ray, at some parameter t >= 0, is inside the box to within the rounding of its own arithmetic
+// (<= 2.4e-7 * (|o| + extent) per coordinate), so a slab test over t >= 0 on the box grown by
+// pad = cull_pad * (|o|_inf + extent) (16x that bound) that MISSES proves the exact test fails.
+// A pre-test that passes decides nothing: box_intersects still runs.  1/d may be approximate.
+struct RayGate { float ix, iy, iz, pad; };
+
+RT_FN float approx_rcp(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+
+RT_FN RayGate make_gate(float cull_pad, float extent, f3 o, f3 d)
+{
+    RayGate r;
+    r.pad = cull_pad * (fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) + extent);
+    float dx = fabsf(d.x) > 1e-20f ? d.x : (d.x < 0 ? -1e-20f : 1e-20f);
+    float dy = fabsf(d.y) > 1e-20f ? d.y : (d.y < 0 ? -1e-20f : 1e-20f);
+    float dz = fabsf(d.z) > 1e-20f ? d.z : (d.z < 0 ? -1e-20f : 1e-20f);
+    r.ix = approx_rcp(dx); r.iy = approx_rcp(dy); r.iz = approx_rcp(dz);
+    return r;
+}
+
+RT_FN bool gate_maybe(const float* mn, const float* mx, f3 o, const RayGate& r)
+{
+    float ax = ((mn[0] - r.pad) - o.x) * r.ix, bx = ((mx[0] + r.pad) - o.x) * r.ix;
+    float ay = ((mn[1] - r.pad) - o.y) * r.iy, by = ((mx[1] + r.pad) - o.y) * r.iy;
+    float az = ((mn[2] - r.pad) - o.z) * r.iz, bz = ((mx[2] + r.pad) - o.z) * r.iz;
+    float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    float f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    float slack = 8e-6f * fmaxf(fabsf(n), fabsf(f));
+    return (n - slack <= f + slack) && (f + slack >= 0.0f);
 }
 
 // One face of BoundingVolumeBox::intersects (main.cpp:245-296).  For an axis-aligned unit normal
@@ -296,6 +338,22 @@ RT_FN bool bvh_drain(const DScene& S, f3 o, f3 d, const RayCull& rc, Hit& best, 
     return found;
 }
 
+// Gate node i: from the kernel's LDS copy when it is staged there (explicit LDS address space, so
+// the two sources are not folded into one generic-pointer load), else from global memory.
+RT_FN GateNode load_gate(const DScene& S, uint32_t i)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (i < S.num_gates_fast) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const __attribute__((address_space(3))) v4f* p = (const __attribute__((address_space(3))) v4f*)(S.gates_fast + i);
+        union { v4f v[3]; GateNode g; } u;
+        u.v[0] = p[0]; u.v[1] = p[1]; u.v[2] = p[2];
+        return u.g;
+    }
+#endif
+    return S.gates[i];
+}
+
 // ---- one closest-hit query over world->scene ("one ray") ----------------------------------------
 // MODE 0: closest hit (`for obj in scene: hit |= obj->hit(ray, rec)`, main.cpp:1645-1648, 1390-1393,
 //         1457-1460, 1548-1551) with rec.t starting at tmax.
@@ -308,14 +366,14 @@ template <int MODE, bool STATS, bool DEFER = false>
 RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& shadow, Stack st, Counters& cnt)
 {
     best.t = tmax; best.prim = H_MISS; best.u = 0; best.v = 0; best.rank = 0;
-    RayCull rc = make_cull(S, o, d);
+    const RayGate rg = make_gate(S.cull_pad, S.extent, o, d);
     bool shadowed = false, transparentOnly = true;
     if (S.debug & 2u) { shadow = 1.0f; return 0; }
     uint32_t cur_item = 0;
     uint32_t i = 0, sp = 0;
     const uint32_t n = S.num_gates;
     while (i < n) {
-        const GateNode g = S.gates[i];
+        const GateNode g = load_gate(S, i);
         if (MODE == 1 && g.item != cur_item) {
             if (best.prim != H_MISS) {
                 shadowed = true;
@@ -330,27 +388,25 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
             best.t = tmax; best.prim = H_MISS;
             cur_item = g.item;
         }
-        switch (g.kind) {
+        switch (g.kind & G_KIND_MASK) {
         case G_GROUP:
             i++;
             break;
         case G_GATED:
             if (STATS) cnt.gates++;
-            i = box_intersects(g.mn, g.mx, o, d) ? i + 1 : g.skip;
+            i = ((g.kind & G_SAME_BOX) || (gate_maybe(g.mn, g.mx, o, rg) && box_intersects(g.mn, g.mx, o, d))) ? i + 1 : g.skip;
             break;
         case G_PLANE: {
-            q4 p0 = S.planes[g.a * 2], p1 = S.planes[g.a * 2 + 1];
             float t;
-            if (plane_t(xyz(p0), xyz(p1), o, d, t) && closer(t, g.rank, best)) {
+            if (plane_t(F3(g.mn[0], g.mn[1], g.mn[2]), F3(g.mx[0], g.mx[1], g.mx[2]), o, d, t) && closer(t, g.rank, best)) {
                 best.t = t; best.prim = H_PLANE | g.a; best.rank = g.rank;
             }
             i++;
             break;
         }
         case G_SPHERE: {
-            q4 s0 = S.spheres[g.a * 2], s1 = S.spheres[g.a * 2 + 1];
             float t;
-            if (sphere_t(xyz(s0), s1.x, o, d, t) && closer(t, g.rank, best)) {
+            if (sphere_t(F3(g.mn[0], g.mn[1], g.mn[2]), g.mx[0], o, d, t) && closer(t, g.rank, best)) {
                 best.t = t; best.prim = H_SPHERE | g.a; best.rank = g.rank;
             }
             i++;
@@ -369,9 +425,10 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
         }
         default: { // G_MESH: gate, then defer its triangle BVH to the shared drain loop
             if (STATS) cnt.gates++;
-            if (box_intersects(g.mn, g.mx, o, d)) {
+            if ((g.kind & G_SAME_BOX) || (gate_maybe(g.mn, g.mx, o, rg) && box_intersects(g.mn, g.mx, o, d))) {
                 st.p[(sp++) * st.stride] = g.a;
                 if (sp >= (DEFER ? RT_DEFER_ROOTS : RT_PENDING_MAX)) {
+                    const RayCull rc = make_cull(S, o, d);
                     if (MODE == 1 && S.item_opaque[g.item]) {
                         if (bvh_drain<STATS, true>(S, o, d, rc, best, st, sp, cnt)) { shadowed = true; transparentOnly = false; i = n; break; }
                     } else {
@@ -384,7 +441,8 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
         }
         }
         // end of the walk, or (shadow query) end of a world->scene entry: drain the deferred meshes
-        if (!DEFER && sp > 0 && (i >= n || (MODE == 1 && S.gates[i].item != cur_item))) {
+        if (!DEFER && sp > 0 && (i >= n || (MODE == 1 && load_gate(S, i).item != cur_item))) {
+            const RayCull rc = make_cull(S, o, d);
             if (MODE == 1 && S.item_opaque[cur_item]) {
                 if (bvh_drain<STATS, true>(S, o, d, rc, best, st, sp, cnt)) { shadowed = true; transparentOnly = false; i = n; }
             } else {
@@ -515,6 +573,44 @@ RT_FN f3 texture_colour(const DScene& S, int tex, float u, float v)
 
 // ---- ambient occlusion ray (Ambient::L, main.cpp:1361-1393; sampleHemisphere :4-19;
 //      rotationMatToSpace :21-34 and the mat4*vec4 product) ---------------------------------------
+// (double)r / (double)RT_RAND_MAX without an fp64 division: with y = RN(1/M), q = r*y,
+// rem = fma(-q, M, r) (exact) the step fma(rem, y, q) is the correctly rounded quotient (Markstein);
+// checked against the division for all 2^31 numerators (tests/test_emul.py samples it).
+RT_FN double div_rand_max(int r)
+{
+    const double M = 2147483647.0, y = 0x1.00000002p-31;
+    double a = (double)r, q = a * y;
+    double rem = fma(-q, M, a);
+    return fma(rem, y, q);
+}
+
+// sin and cos of x in [0, 2*pi] (here: float phi widened to double) to ~1e-16, for rounding to
+// float.  Cody-Waite reduction by pi/2 (k <= 4, so k*PIO2_HI is exact) + the fdlibm kernel
+// polynomials.  Replaces two separate library calls (and their large-argument paths).
+RT_FN void sincos_f64(double x, double& sn, double& cs)
+{
+    const double k = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632673412561417e+00, x);
+    r = fma(-k, 6.07710050650619224932e-11, r);
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double s = fma(r * z, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double c = fma(z * z, pc, fma(z, -0.5, 1.0));
+    const int n = (int)k & 3;
+    sn = (n & 1) ? c : s; cs = (n & 1) ? s : c;
+    if (n & 2) sn = -sn;
+    if ((n + 1) & 2) cs = -cs;
+}
+
 RT_FN void ao_ray(const rt_ambient& A, f3 P, f3 N, uint32_t seed, uint32_t pixel, uint32_t sample,
                   uint32_t ao_call, uint32_t k, f3& o, f3& dir)
 {
@@ -523,12 +619,14 @@ RT_FN void ao_ray(const rt_ambient& A, f3 P, f3 N, uint32_t seed, uint32_t pixel
     uint32_t ctr = 2u + ao_call * 2u * n * n + k * 2u;
     float grid = 1.0f / (float)n;
     int r0 = (int)rt_rand31(seed, pixel, sample, ctr), r1 = (int)rt_rand31(seed, pixel, sample, ctr + 1);
-    float sampleX = (float)x * grid + (float)(((double)r0 / (double)RT_RAND_MAX) * (double)grid);
-    float sampleY = (float)y * grid + (float)(((double)r1 / (double)RT_RAND_MAX) * (double)grid);
+    float sampleX = (float)x * grid + (float)((div_rand_max(r0)) * (double)grid);
+    float sampleY = (float)y * grid + (float)((div_rand_max(r1)) * (double)grid);
     float r = sqrtf(1.0f - sampleX * sampleX);
     float phi = 2 * 3.14159265358979323846264338327950288f * sampleY;
     // glibc's cosf/sinf are (almost always) correctly rounded; get the same bits from fp64
-    f3 h = F3((float)cos((double)phi) * r, sampleX, (float)sin((double)phi) * r);
+    double sn, cs;
+    sincos_f64((double)phi, sn, cs);
+    f3 h = F3((float)cs * r, sampleX, (float)sn * r);
     f3 w = normalize(N);
     f3 u = normalize(cross(w, F3(0.053f, 1.0f, 0.0332f)));
     f3 v = cross(w, u);

@@ -41,6 +41,18 @@ __device__ inline void flush_counters(const Counters& c, unsigned long long* sta
     }
 }
 
+// The first RT_LDS_GATES nodes of the gate array (all of it for the reference's scenes) are staged
+// in LDS once per block: the walk reads one 48-byte node per step, every lane of a wave mostly the
+// same one, and an LDS broadcast read has a fraction of the L1/L2 round trip's latency.
+#define RT_LDS_GATES 64
+__device__ inline void stage_gates(DScene& S, GateNode* s_gates)
+{
+    const uint32_t nf = S.num_gates < RT_LDS_GATES ? S.num_gates : RT_LDS_GATES;
+    for (uint32_t k = threadIdx.x; k < nf * 3u; k += RT_BLOCK) ((q4*)s_gates)[k] = ((const q4*)S.gates)[k];
+    __syncthreads();
+    S.gates_fast = s_gates; S.num_gates_fast = nf;
+}
+
 __global__ void __launch_bounds__(RT_BLOCK) k_raygen(DScene S, RenderArgs A, Batch B, uint32_t n)
 {
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) raygen_item(S, A, B, i);
@@ -50,6 +62,8 @@ template <bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK) k_trace(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
 {
     __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_BLOCK];
+    __shared__ GateNode s_gates[RT_LDS_GATES];
+    stage_gates(S, s_gates);
     const uint32_t n = depth == 0 ? fixed_n : B.counters[C_QUEUE + depth];
     Stack st{s_stack + threadIdx.x, RT_BLOCK};
     Counters cnt{0, 0, 0};
@@ -68,6 +82,8 @@ template <bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene S, RenderArgs A, Batch B, int depth)
 {
     __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_BLOCK];
+    __shared__ GateNode s_gates[RT_LDS_GATES];
+    stage_gates(S, s_gates);
     const uint32_t n = B.counters[C_SH + depth];
     Stack st{s_stack + threadIdx.x, RT_BLOCK};
     Counters cnt{0, 0, 0};
@@ -80,6 +96,8 @@ template <bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B, int depth)
 {
     __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_BLOCK];
+    __shared__ GateNode s_gates[RT_LDS_GATES];
+    stage_gates(S, s_gates);
     const uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
     const uint32_t n = B.counters[C_AO + depth] * n2;
     Stack st{s_stack + threadIdx.x, RT_BLOCK};
@@ -624,6 +642,7 @@ int rt_scene_commit(rt_scene* s)
     if ((rc = up(H.texels.data(), H.texels.size(), (const void**)&D.texels))) return rc;
     if ((rc = up(H.item_opaque.data(), H.item_opaque.size(), (const void**)&D.item_opaque))) return rc;
     D.num_gates = (uint32_t)H.gates.size();
+    D.gates_fast = nullptr; D.num_gates_fast = 0;
     D.num_lights = (uint32_t)H.dlights.size();
     D.num_textures = (uint32_t)H.dtextures.size();
     D.num_items = (uint32_t)H.item_opaque.size();

@@ -414,8 +414,10 @@ void HostScene::emit_shape(const rt_shape_ref& r, uint32_t item, uint32_t rank_b
     GateNode g{};
     g.item = item; g.rank = rank_base;
     switch (r.kind) {
-    case RT_SHAPE_PLANE: g.kind = G_PLANE; g.a = r.index; g.skip = (uint32_t)gates.size() + 1; gates.push_back(g); break;
-    case RT_SHAPE_SPHERE: g.kind = G_SPHERE; g.a = r.index; g.skip = (uint32_t)gates.size() + 1; gates.push_back(g); break;
+    case RT_SHAPE_PLANE: g.kind = G_PLANE; g.a = r.index; std::memcpy(g.mn, planes[r.index].point, 12); std::memcpy(g.mx, planes[r.index].normal, 12); g.skip = (uint32_t)gates.size() + 1; gates.push_back(g); break;
+    case RT_SHAPE_SPHERE: g.kind = G_SPHERE; g.a = r.index; std::memcpy(g.mn, spheres[r.index].centre, 12);
+        g.mx[0] = spheres[r.index].radius * spheres[r.index].radius; g.mx[1] = spheres[r.index].radius; g.mx[2] = 0.0f;   // mRadiusSqr{radius*radius}
+        g.skip = (uint32_t)gates.size() + 1; gates.push_back(g); break;
     case RT_SHAPE_TRIANGLE: g.kind = G_TRI; g.a = add_triangle_slot(r.index, rank_base); g.skip = (uint32_t)gates.size() + 1; gates.push_back(g); break;
     case RT_SHAPE_MESH: emit_mesh(r.index, item, rank_base); break;
     case RT_SHAPE_MULTIMESH: {
@@ -512,6 +514,24 @@ int HostScene::build()
         item_opaque.push_back(subtree_opaque(scene[i]) ? 1 : 0);
     }
     if (item_opaque.empty()) item_opaque.push_back(1);
+    // A gate whose box is bit-identical to the enclosing gate's (a MultiMesh of one Mesh) repeats a test
+    // that has just passed: flag it.  `extent` (the scale of the conservative paddings) covers gate boxes too.
+    {
+        std::vector<uint32_t> open_gates;   // enclosing gated nodes of the node being visited
+        for (uint32_t i = 0; i < gates.size(); ++i) {
+            while (!open_gates.empty() && gates[open_gates.back()].skip <= i) open_gates.pop_back();
+            GateNode& g = gates[i];
+            const uint32_t kind = g.kind & G_KIND_MASK;
+            if (kind != G_GATED && kind != G_MESH) continue;
+            for (int k = 0; k < 3; ++k)
+                if (std::isfinite(g.mn[k]) && std::isfinite(g.mx[k])) extent = std::max(extent, std::max(std::fabs(g.mn[k]), std::fabs(g.mx[k])));
+            if (!open_gates.empty()) {
+                const GateNode& e = gates[open_gates.back()];
+                if (std::memcmp(e.mn, g.mn, 12) == 0 && std::memcmp(e.mx, g.mx, 12) == 0) g.kind |= G_SAME_BOX;
+            }
+            if (kind == G_GATED) open_gates.push_back(i);
+        }
+    }
     if (bvh_max_depth > (uint32_t)kMaxDepth + 1) { error = "triangle BVH deeper than the traversal stack"; return RT_ERR_UNSUPPORTED; }
     quantize_nodes();
 

@@ -84,7 +84,7 @@ int emul_render(const rt_scene_desc* d, const rt_camera* cam, const rt_params* p
 
     LoopBackend be;
     DScene& S = be.S;
-    S.gates = H.gates.data(); S.num_gates = (uint32_t)H.gates.size();
+    S.gates = H.gates.data(); S.num_gates = (uint32_t)H.gates.size(); S.gates_fast = nullptr; S.num_gates_fast = 0;
     S.planes = H.planes4.data(); S.spheres = H.spheres4.data(); S.tris = H.tris4.data();
     S.tri_attr = H.attr4.data(); S.nodes = H.nodes4.data();
     S.materials = H.dmaterials.data(); S.lights = H.dlights.data(); S.num_lights = (uint32_t)H.dlights.size();
