@@ -96,7 +96,7 @@ struct DScene {
 // BVH child reference: bit31 = leaf, bits 28..30 = triangle count-1, bits 0..27 = first slot
 enum : uint32_t { REF_LEAF = 0x80000000u, REF_NONE = 0x7FFFFFFFu };
 
-struct Counters { uint32_t nodes, tris, gates; };
+struct Counters { uint32_t nodes, tris, gates, rays; };
 
 struct Stack { uint32_t* p; uint32_t stride; };  // entry i lives at p[i*stride] (LDS: stride = threads per block)
 #define RT_STACK_DEPTH 32

@@ -26,9 +26,16 @@ using namespace rt;
 #define RT_MAX_GRID (256 * 8)
 
 // ---- kernels -------------------------------------------------------------------------------------
+// cls 0 closest-hit queries, 1 shadow rays, 2 AO rays.  The ray counts (cls 1, 2) are always kept;
+// the traversal counters only in the STATS variants.
 template <bool STATS>
 __device__ inline void flush_counters(const Counters& c, unsigned long long* stats, int cls)
 {
+    if (cls != 0) {
+        uint32_t r = c.rays;
+        for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off);
+        if ((threadIdx.x & 63) == 0 && r) atomicAdd(&stats[cls == 1 ? ST_SHADOW : ST_AO], (unsigned long long)r);
+    }
     if (!STATS) return;
     uint32_t n = c.nodes, t = c.tris, g = c.gates;
     for (int off = 32; off > 0; off >>= 1) {
@@ -66,7 +73,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace(DScene S, RenderArgs A, Batc
     stage_gates(S, s_gates);
     const uint32_t n = depth == 0 ? fixed_n : B.counters[C_QUEUE + depth];
     Stack st{s_stack + threadIdx.x, RT_BLOCK};
-    Counters cnt{0, 0, 0};
+    Counters cnt{0, 0, 0, 0};
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK)
         trace_item<STATS>(S, A, B, depth, i, st, cnt);
     flush_counters<STATS>(cnt, B.stats, 0);
@@ -75,7 +82,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace(DScene S, RenderArgs A, Batc
 __global__ void __launch_bounds__(RT_BLOCK) k_prep(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
 {
     const uint32_t n = depth == 0 ? fixed_n : B.counters[C_QUEUE + depth];
-    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) prep_item(S, A, B, depth, i);
+    QCursor qsh{0, 0};
+    // wave-uniform trip count: every lane of a wave takes part in the queue cursor's ballots
+    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        prep_item(S, A, B, depth, i, i < n, qsh);
+    }
+    close_cursor(qsh, B.sh_queue, 0xFFFFFFFFu, B.sh_cap);
 }
 
 template <bool STATS>
@@ -84,31 +97,32 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene S, RenderArgs A, Bat
     __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_BLOCK];
     __shared__ GateNode s_gates[RT_LDS_GATES];
     stage_gates(S, s_gates);
-    const uint32_t n = B.counters[C_SH + depth];
+    const uint32_t n = B.counters[C_SH + depth] < B.sh_cap ? B.counters[C_SH + depth] : B.sh_cap;
     Stack st{s_stack + threadIdx.x, RT_BLOCK};
-    Counters cnt{0, 0, 0};
+    Counters cnt{0, 0, 0, 0};
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK)
         shadow_item<STATS>(S, A, B, depth, i, st, cnt);
     flush_counters<STATS>(cnt, B.stats, 1);
 }
 
 template <bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B, int depth)
+__global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
 {
     __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_BLOCK];
     __shared__ GateNode s_gates[RT_LDS_GATES];
     stage_gates(S, s_gates);
     const uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
-    const uint32_t n = B.counters[C_AO + depth] * n2;
+    const uint32_t nslots = depth == 0 ? fixed_n : B.counters[C_QUEUE + depth];
+    const uint32_t n = nslots * n2;
     Stack st{s_stack + threadIdx.x, RT_BLOCK};
-    Counters cnt{0, 0, 0};
+    Counters cnt{0, 0, 0, 0};
     QCursor qc{0, 0};
     // wave-uniform trip count: every lane of a wave takes part in the queue cursor's ballots
     for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
         const uint32_t i = base + threadIdx.x;
-        ao_item<STATS>(S, A, B, depth, i, i < n, st, cnt, qc);
+        ao_item<STATS>(S, A, B, depth, i, nslots, i < n, st, cnt, qc);
     }
-    close_cursor(B, qc);
+    close_cursor(qc, B.bq_roots, (uint32_t)REF_NONE, B.bq_cap);
     flush_counters<STATS>(cnt, B.stats, 2);
 }
 
@@ -151,7 +165,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
     if (n > B.bq_cap) n = B.bq_cap;
     uint32_t* next = &B.counters[next_counter];
     uint32_t* pend = s_pend + threadIdx.x;
-    Counters cnt{0, 0, 0};
+    Counters cnt{0, 0, 0, 0};
     const uint32_t lane = threadIdx.x & 63u;
     f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
     RayCull rc = {};
@@ -280,13 +294,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_resolve(DScene S, RenderArgs A, Ba
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) resolve_item(S, A, B, i);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const unsigned n2 = (unsigned)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
-        unsigned long long sh = 0, ao = 0, bo = 0;
-        for (int d = 0; d < levels_run; ++d) {
-            sh += B.counters[C_SH + d];
-            ao += (unsigned long long)B.counters[C_AO + d] * n2;
-            if (d > 0) bo += B.counters[C_QUEUE + d];
-        }
-        B.stats[ST_SHADOW] += sh; B.stats[ST_AO] += ao; B.stats[ST_BOUNCE] += bo;
+        unsigned long long bo = 0;
+        for (int d = 1; d < levels_run; ++d) bo += B.counters[C_QUEUE + d];
+        B.stats[ST_BOUNCE] += bo;   // shadow and AO rays are counted by their kernels
     }
 }
 
@@ -420,12 +430,12 @@ struct GpuBackend {
             else hipLaunchKernelGGL(k_shadow<false>, dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, A, B, d);
         });
     }
-    void ao(const RenderArgs& A, int d)
+    void ao(const RenderArgs& A, int d, uint32_t n)
     {
         if (S.ambient.occlusion_samples <= 0) return;
         timed(RT_K_AO, [&] {
-            if (stats) hipLaunchKernelGGL(k_ao<true>, dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, A, B, d);
-            else hipLaunchKernelGGL(k_ao<false>, dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, A, B, d);
+            if (stats) hipLaunchKernelGGL(k_ao<true>, dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
+            else hipLaunchKernelGGL(k_ao<false>, dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
         });
     }
     void shade(const RenderArgs& A, int d, uint32_t n) { timed(RT_K_SHADE, [&] { hipLaunchKernelGGL(k_shade, dim3(grid_d(d, n)), dim3(RT_BLOCK), 0, stream, S, A, B, d, n); }); }
@@ -446,7 +456,9 @@ size_t carve_batch(Batch& B, char* base, uint32_t P, int levels, uint32_t nl, ui
     B.pstate = (uint32_t*)take(4ull * P);
     B.ao_queue = (uint32_t*)take(4ull * P);
     B.ao_slot = (uint32_t*)take(4ull * P);
-    B.sh_queue = (uint32_t*)take(4ull * P * nl);
+    // worst case of the chunked appends: <= 63 holes per RT_SHCHUNK-slot chunk + one open chunk per wave of k_prep
+    B.sh_cap = (uint32_t)std::min<size_t>((size_t)P * nl * RT_SHCHUNK / (RT_SHCHUNK - 63) + RT_SHCHUNK + (size_t)RT_MAX_GRID * (RT_BLOCK / 64) * RT_SHCHUNK, 0xFFFF0000u);
+    B.sh_queue = (uint32_t*)take(4ull * B.sh_cap);
     B.ao_t = (float*)take(4ull * P * (n2 ? n2 : 1));
     B.sh_res = (float*)take(4ull * P * nl);
     B.lvl = (q4*)take(sizeof(q4) * (size_t)P * levels);

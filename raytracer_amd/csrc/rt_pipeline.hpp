@@ -46,6 +46,7 @@ struct Batch {
     q4* bq_c;              // closest-hit queries only: {bits(prim), bits(rank), u, v} of that closest hit
     uint32_t* bq_roots;    // [k * bq_cap + item]: mesh-BVH roots, terminated by REF_NONE when fewer than RT_DEFER_ROOTS
     uint32_t bq_cap;       // items the queue can hold (rays beyond it are traversed inline)
+    uint32_t sh_cap;       // entries sh_queue can hold (holes of the chunked appends included)
     uint32_t* bq_spill;    // GPU: k_bvh's stack entries beyond its short LDS stack, [entry][global lane]
     uint32_t* counters;    // C_TOTAL
     unsigned long long* stats; // ST_TOTAL, accumulated over the whole render
@@ -149,38 +150,57 @@ RT_FN bool defer_bvh(const DScene& S, const Batch& B, uint32_t counter, f3 o, f3
     return true;
 }
 
-// AO flavour of defer_bvh for the GPU's hottest append (one per AO ray that meets a Mesh).  A single
-// counter word serves only ~90 returning atomics per microsecond, so a wave reserves RT_QCHUNK
-// consecutive slots with ONE atomic and hands them out by ballot + prefix sum from a wave-uniform
-// cursor.  Slots a wave reserves but never fills (the tail of a chunk) are marked as holes (no
-// roots); k_bvh skips them.  Must be called by all 64 lanes of the wave (`want` selects).
+// Chunked queue append for the GPU's hot queues.  A single counter word serves only ~90 returning
+// atomics per microsecond, so a wave reserves CHUNK consecutive slots with ONE atomic and hands
+// them out by ballot + prefix sum from a wave-uniform cursor.  Slots a wave reserves but never
+// fills (the tail of a chunk) are marked as holes (`hole_value` in `holes[slot]`); the consumer
+// skips them.  Must be called by all 64 lanes of the wave (`want` selects).  Returns the slot of a
+// lane that wants one; a slot >= cap must not be written.
 struct QCursor { uint32_t next, end; };
-#define RT_QCHUNK 1024u
+#define RT_QCHUNK 1024u    // BVH work queue (k_ao)
+#define RT_SHCHUNK 256u    // shadow queue (k_prep)
 
+template <uint32_t CHUNK>
+RT_FN uint32_t chunk_append(uint32_t* counter, bool want, QCursor& qc, uint32_t* holes, uint32_t hole_value, uint32_t cap)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long mask = __ballot(want);
+    const uint32_t nw = (uint32_t)__popcll(mask);
+    if (nw == 0) return 0xFFFFFFFFu;
+    const uint32_t lane = __lane_id();
+    if (qc.next + nw > qc.end) {
+        const uint32_t rem = qc.end - qc.next;   // < 64
+        if (lane < rem && qc.next + lane < cap) holes[qc.next + lane] = hole_value;
+        uint32_t b0 = 0;
+        if (lane == 0) b0 = atomicAdd(counter, CHUNK);
+        b0 = __shfl(b0, 0);
+        qc.next = b0; qc.end = b0 + CHUNK;
+    }
+    const uint32_t slot = qc.next + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    qc.next += nw;
+    return slot;
+#else
+    (void)qc; (void)holes; (void)hole_value; (void)cap;
+    return want ? (*counter)++ : 0xFFFFFFFFu;
+#endif
+}
+
+// marks the unused rest of the wave's last chunk as holes (GPU; all lanes of the wave)
+RT_FN void close_cursor(const QCursor& qc, uint32_t* holes, uint32_t hole_value, uint32_t cap)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (uint32_t s = qc.next + __lane_id(); s < qc.end && s < cap; s += 64u) holes[s] = hole_value;
+#else
+    (void)qc; (void)holes; (void)hole_value; (void)cap;
+#endif
+}
+
+// AO flavour of defer_bvh: one append per AO ray that meets a Mesh, through the chunked cursor.
 template <bool STATS>
 RT_FN bool defer_ao(const DScene& S, const Batch& B, uint32_t counter, bool want, f3 o, f3 d, Hit& best, uint32_t dst,
                     Stack st, uint32_t sp, Counters& cnt, QCursor& qc)
 {
-    uint32_t slot = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned long long mask = __ballot(want);
-    const uint32_t nw = (uint32_t)__popcll(mask);
-    if (nw == 0) return false;
-    const uint32_t lane = __lane_id();
-    if (qc.next + nw > qc.end) {
-        const uint32_t rem = qc.end - qc.next;   // < 64
-        if (lane < rem && qc.next + lane < B.bq_cap) B.bq_roots[qc.next + lane] = (uint32_t)REF_NONE;
-        uint32_t b0 = 0;
-        if (lane == 0) b0 = atomicAdd(&B.counters[counter], RT_QCHUNK);
-        b0 = __shfl(b0, 0);
-        qc.next = b0; qc.end = b0 + RT_QCHUNK;
-    }
-    slot = qc.next + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    qc.next += nw;
-#else
-    (void)qc;
-    if (want) slot = B.counters[counter]++;
-#endif
+    const uint32_t slot = chunk_append<RT_QCHUNK>(&B.counters[counter], want, qc, B.bq_roots, (uint32_t)REF_NONE, B.bq_cap);
     if (!want) return false;
     if (slot >= B.bq_cap) {
         RayCull rc = make_cull(S, o, d);
@@ -193,16 +213,6 @@ RT_FN bool defer_ao(const DScene& S, const Batch& B, uint32_t counter, bool want
     for (uint32_t k = 0; k < sp; ++k) B.bq_roots[(size_t)k * B.bq_cap + slot] = st.p[k * st.stride];
     if (sp < RT_DEFER_ROOTS) B.bq_roots[(size_t)sp * B.bq_cap + slot] = (uint32_t)REF_NONE;
     return true;
-}
-
-// marks the unused rest of the wave's last chunk as holes (GPU; all lanes of the wave)
-RT_FN void close_cursor(const Batch& B, const QCursor& qc)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    for (uint32_t s = qc.next + __lane_id(); s < qc.end && s < B.bq_cap; s += 64u) B.bq_roots[s] = (uint32_t)REF_NONE;
-#else
-    (void)B; (void)qc;
-#endif
 }
 
 template <bool STATS>
@@ -240,11 +250,15 @@ RT_FN void bvh_item(const DScene& S, const Batch& B, uint32_t idx, Stack st, Cou
     else { q4 r = {best.t, u2f(best.prim), best.u, best.v}; B.hit[dst] = r; }
 }
 
-RT_FN void prep_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx)
+// Returns true when the path's material consumes shadow rays (Specular / Textured); P and N are then
+// the hit point and shading normal.  The AO "queue" is positional: slot = idx, no append.
+RT_FN bool prep_body(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, uint32_t& p_out, f3& P_out, f3& N_out)
 {
+    B.ao_queue[idx] = 0xFFFFFFFFu;
     uint32_t p = item_path(A, B, depth, idx);
     PathPix px = path_of(A, p);
-    if (depth == 0 && !px.valid) return;
+    p_out = p;
+    if (depth == 0 && !px.valid) return false;
     q4 h4 = B.hit[p];
     Hit h; h.t = h4.x; h.prim = f2u(h4.y); h.u = h4.z; h.v = h4.w;
     size_t li = (size_t)depth * B.P + p;
@@ -256,7 +270,7 @@ RT_FN void prep_item(const DScene& S, const RenderArgs& A, const Batch& B, int d
             if (A.out_prim) A.out_prim[px.out] = 0xFFFFFFFFu;
             if (A.out_t) A.out_t[px.out] = h.t;
         }
-        return;
+        return false;
     }
     Surface sf = surface_of(S, h, o, d);
     if (depth == 0 && px.j == 0) {
@@ -278,22 +292,13 @@ RT_FN void prep_item(const DScene& S, const RenderArgs& A, const Batch& B, int d
         ps = ((a + 1u) & 0xFFu) | (a << 8);
         B.pstate[p] = ps;
         if (M.ka != 0.0f) {   // ka == 0 multiplies the (finite) occlusion factor away: no rays needed
-            slot = queue_slot(&B.counters[C_AO + depth]);
+            slot = idx;
             B.ao_queue[slot] = p;
         }
     }
     B.ao_slot[p] = slot;
 
-    if (M.kind == RT_MAT_SPECULAR || M.kind == RT_MAT_TEXTURED) {
-        // the shadow ray is only consumed when n.wi > 0 (main.cpp:1227-1237, 1281-1293)
-        for (uint32_t l = 0; l < S.num_lights; ++l) {
-            f3 wi = normalize(light_direction(S.lights[l], P));
-            if (dot(sf.normal, wi) > 0.0f) {
-                uint32_t e = queue_slot(&B.counters[C_SH + depth]);
-                B.sh_queue[e] = p * S.num_lights + l;
-            }
-        }
-    }
+    P_out = P; N_out = sf.normal;
 
     if (M.kind == RT_MAT_MIRROR || M.kind == RT_MAT_REFRACTION) {
         B.lvl_kind[li] = M.kind == RT_MAT_MIRROR ? LK_MIRROR : LK_REFRACT;
@@ -318,12 +323,34 @@ RT_FN void prep_item(const DScene& S, const RenderArgs& A, const Batch& B, int d
     } else {
         B.lvl_kind[li] = LK_TERMINAL;
     }
+    return M.kind == RT_MAT_SPECULAR || M.kind == RT_MAT_TEXTURED;
+}
+
+// `valid` = idx addresses a path; all 64 lanes of a wave call this together (GPU): the shadow-ray
+// appends go through the wave's chunked cursor.
+RT_FN void prep_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, bool valid, QCursor& qsh)
+{
+    uint32_t p = 0;
+    f3 P = F3(0, 0, 0), N = F3(0, 0, 1);
+    const bool lit = valid && prep_body(S, A, B, depth, idx, p, P, N);
+    // the shadow ray is only consumed when n.wi > 0 (main.cpp:1227-1237, 1281-1293)
+    for (uint32_t l = 0; l < S.num_lights; ++l) {
+        bool want = false;
+        if (lit) {
+            f3 wi = normalize(light_direction(S.lights[l], P));
+            want = dot(N, wi) > 0.0f;
+        }
+        const uint32_t e = chunk_append<RT_SHCHUNK>(&B.counters[C_SH + depth], want, qsh, B.sh_queue, 0xFFFFFFFFu, B.sh_cap);
+        if (want && e < B.sh_cap) B.sh_queue[e] = p * S.num_lights + l;   // sh_cap covers the worst case (carve_batch)
+    }
 }
 
 template <bool STATS>
 RT_FN void shadow_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, Stack st, Counters& cnt)
 {
     uint32_t e = B.sh_queue[idx];
+    if (e == 0xFFFFFFFFu) return;   // hole left by the chunked appends
+    cnt.rays++;
     uint32_t p = e / S.num_lights, l = e % S.num_lights;
     q4 o4 = B.ray_o[depth & 1][p], d4 = B.ray_d[depth & 1][p];
     f3 P = xyz(o4) + xyz(d4) * B.hit[p].x;
@@ -336,7 +363,7 @@ RT_FN void shadow_item(const DScene& S, const RenderArgs& A, const Batch& B, int
 }
 
 template <bool STATS>
-RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, bool valid, Stack st,
+RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, uint32_t nslots, bool valid, Stack st,
                    Counters& cnt, QCursor& qc)
 {
     // stratum-major order: a wave traces the same stratum (x,y) of 64 neighbouring hits, whose
@@ -344,11 +371,15 @@ RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int dep
     f3 o = F3(0, 0, 0), dir = F3(0, 0, 1);
     Hit h = {}; float sh;
     uint32_t dst = 0, sp = 0;
+    uint32_t slot = 0, k = 0, p = 0xFFFFFFFFu;
+    if (valid) {   // slot = position of the path in this depth's path list; paths without AO rays hold no path id
+        slot = idx % nslots; k = idx / nslots;
+        p = B.ao_queue[slot];
+        valid = p != 0xFFFFFFFFu;
+    }
     if (valid) {
-        uint32_t nslots = B.counters[C_AO + depth];
+        cnt.rays++;
         uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
-        uint32_t slot = idx % nslots, k = idx / nslots;
-        uint32_t p = B.ao_queue[slot];
         PathPix px = path_of(A, p);
         q4 o4 = B.ray_o[depth & 1][p], d4 = B.ray_d[depth & 1][p];
         f3 P = xyz(o4) + xyz(d4) * B.hit[p].x;
@@ -507,7 +538,7 @@ void render_frame(Backend& be, RenderArgs A, uint32_t owned_tiles, uint32_t tile
             be.bvh_trace(A, d);
             be.prep(A, d, paths);
             be.shadow(A, d);
-            be.ao(A, d);
+            be.ao(A, d, paths);
             be.bvh_ao(A, d);
             be.shade(A, d, paths);
         }

@@ -34,25 +34,24 @@ struct LoopBackend {
         Stack st{stack.data(), 1};
         for (uint32_t i = 0, n = std::min(B.counters[C_BQA + d], B.bq_cap); i < n; ++i) bvh_item<true, true>(S, B, i, st, cnt[2]);
     }
-    void prep(const RenderArgs& A, int d, uint32_t fixed) { for (uint32_t i = 0, n = count(d, fixed); i < n; ++i) prep_item(S, A, B, d, i); }
+    void prep(const RenderArgs& A, int d, uint32_t fixed) { QCursor q{0, 0}; for (uint32_t i = 0, n = count(d, fixed); i < n; ++i) prep_item(S, A, B, d, i, true, q); }
     void shadow(const RenderArgs& A, int d) {
         Stack st{stack.data(), 1};
         for (uint32_t i = 0, n = B.counters[C_SH + d]; i < n; ++i) shadow_item<true>(S, A, B, d, i, st, cnt[1]);
     }
-    void ao(const RenderArgs& A, int d) {
+    void ao(const RenderArgs& A, int d, uint32_t fixed) {
         Stack st{stack.data(), 1};
         uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
         QCursor qc{0, 0};
-        for (uint32_t i = 0, n = B.counters[C_AO + d] * n2; i < n; ++i) ao_item<true>(S, A, B, d, i, true, st, cnt[2], qc);
+        const uint32_t nslots = count(d, fixed);
+        for (uint32_t i = 0, n = nslots * n2; i < n; ++i) ao_item<true>(S, A, B, d, i, nslots, true, st, cnt[2], qc);
     }
     void shade(const RenderArgs& A, int d, uint32_t fixed) { for (uint32_t i = 0, n = count(d, fixed); i < n; ++i) shade_item(S, A, B, d, i); }
     void resolve(const RenderArgs& A, uint32_t n) {
         for (uint32_t i = 0; i < n; ++i) resolve_item(S, A, B, i);
-        for (int d = 0; d < A.levels; ++d) {
-            B.stats[ST_SHADOW] += B.counters[C_SH + d];
-            B.stats[ST_AO] += (unsigned long long)B.counters[C_AO + d] * (unsigned)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
-            if (d > 0) B.stats[ST_BOUNCE] += B.counters[C_QUEUE + d];
-        }
+        for (int d = 1; d < A.levels; ++d) B.stats[ST_BOUNCE] += B.counters[C_QUEUE + d];
+        B.stats[ST_SHADOW] += cnt[1].rays; B.stats[ST_AO] += cnt[2].rays;
+        cnt[1].rays = cnt[2].rays = 0;
     }
 };
 } // namespace
@@ -118,6 +117,7 @@ int emul_render(const rt_scene_desc* d, const rt_camera* cam, const rt_params* p
     std::vector<unsigned long long> stats(ST_TOTAL, 0);
     // a deliberately small queue so the inline fallback of defer_bvh is exercised too
     B.bq_cap = P * (n2 ? n2 : 1) / 3 + 1;
+    B.sh_cap = (uint32_t)shq.size();
     std::vector<q4> bqa(B.bq_cap), bqb(B.bq_cap), bqc(B.bq_cap); std::vector<uint32_t> bqr((size_t)B.bq_cap * RT_DEFER_ROOTS);
     B.bq_a = bqa.data(); B.bq_b = bqb.data(); B.bq_c = bqc.data(); B.bq_roots = bqr.data();
     B.ray_o[0] = ro0.data(); B.ray_o[1] = ro1.data(); B.ray_d[0] = rd0.data(); B.ray_d[1] = rd1.data();
