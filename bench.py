@@ -131,13 +131,14 @@ def main():
         value = rays_total / (ms_per_step * 1e-3) / 1e6
         # roofline of the dominant kernel = the compacted triangle-BVH traversal of the ambient-
         # occlusion rays (k_bvh<AO>), rank 0's launches.  Algorithmic bytes per ray it processes:
-        # B = 96 + 64*V + 48*T (ray+hit records, V 64-byte nodes, T 48-byte triangles;
-        # V and T come from the counting pass and count cache hits too).
+        # B = 96 + 32*V + 48*T (SURVEY.md 8d's formula with this build's node size: ray+hit records,
+        # V 32-byte quantised nodes, T 48-byte triangles; V and T come from the counting pass and
+        # count cache hits too).
         k = capi.RT_K_NAMES.index("ao_bvh")
         units = float(st_count.bvh_rays[2])
         V = st_count.nodes[2] / max(1.0, units)
         T = st_count.tris[2] / max(1.0, units)
-        b_ray = 96.0 + 64.0 * V + 48.0 * T
+        b_ray = 96.0 + 32.0 * V + 48.0 * T
         k_ms = kernel_ms[k] / args.steps
         k_launches = launches[k] / args.steps
         achieved = (units * b_ray) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0

@@ -159,7 +159,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
     };
     auto pop = [&](uint32_t& sp_) -> uint32_t {
         --sp_;
-        return sp_ < RT_LDS_STACK ? s_stack[sp_ * RT_BLOCK + threadIdx.x] : spill[(size_t)(sp_ - RT_LDS_STACK) * spill_stride];
+        // the LDS read is unconditional (clamped) so that the two sources stay two instructions
+        // instead of one generic-pointer (flat) load
+        uint32_t x = s_stack[(sp_ < RT_LDS_STACK ? sp_ : RT_LDS_STACK - 1) * RT_BLOCK + threadIdx.x];
+        if (sp_ >= RT_LDS_STACK) x = spill[(size_t)(sp_ - RT_LDS_STACK) * spill_stride];
+        return x;
     };
     uint32_t n = B.counters[counter];
     if (n > B.bq_cap) n = B.bq_cap;
@@ -198,15 +202,17 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
                 const uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                 if (idx < lim) {   // items at or beyond the chunk end are left for the next refill
                     const q4 a = B.bq_a[idx], b = B.bq_b[idx];
-                    o = xyz(a); d = xyz(b); dst = f2u(b.w);
+                    const uint32_t root0 = B.bq_roots[idx];   // REF_NONE marks a hole
+                    o = xyz(a); d = xyz(b);
+                    const uint32_t nroots = (f2u(b.w) >> 29) + 1u;
+                    dst = f2u(b.w) & 0x1FFFFFFFu;
                     best.t = a.w; best.prim = H_MISS; best.rank = 0; best.u = 0; best.v = 0;
                     if (!AO) { const q4 c = B.bq_c[idx]; best.prim = f2u(c.x); best.rank = f2u(c.y); best.u = c.z; best.v = c.w; }
                     rc = make_cull(S, o, d);
                     sp = 0; npend = 0; tri_left = 0;
-                    for (uint32_t k = 0; k < RT_DEFER_ROOTS; ++k) {
-                        const uint32_t r = B.bq_roots[(size_t)k * B.bq_cap + idx];
-                        if (r == REF_NONE) break;
-                        push(sp, r);
+                    if (root0 != REF_NONE) {
+                        push(sp, root0);
+                        for (uint32_t k = 1; k < nroots; ++k) push(sp, B.bq_roots[(size_t)k * B.bq_cap + idx]);   // rare: one Mesh is the rule
                     }
                     if (sp > 0) { cur = pop(sp); active = true; if (STATS) nrays++; }   // a slot without roots is a hole
                 }
@@ -738,7 +744,8 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
     const uint32_t P = (uint32_t)(tiles_per_batch * per_tile);
     const uint32_t nl = S.num_lights ? S.num_lights : 1;
     const uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
-    if ((uint64_t)P * nl > 0xFFFFFFFFull || (uint64_t)P * (n2 ? n2 : 1) > 0xFFFFFFFFull) { ctx->error = "rt_render: batch too large for 32-bit queue entries; lower batch_paths"; return RT_ERR_UNSUPPORTED; }
+    if ((uint64_t)P * nl > 0xFFFFFFFFull || (uint64_t)P * (n2 ? n2 : 1) >= (1ull << 29)) {   // 29-bit ray ids in the BVH queue items
+        ctx->error = "rt_render: batch too large for 32-bit queue entries; lower batch_paths"; return RT_ERR_UNSUPPORTED; }
 
     Batch B{};
     size_t need = carve_batch(B, nullptr, P, levels_alloc, nl, n2);

@@ -44,7 +44,7 @@ struct Batch {
     q4* bq_a;              // {origin, closest t among the non-mesh primitives}
     q4* bq_b;              // {direction, bits(dst)}
     q4* bq_c;              // closest-hit queries only: {bits(prim), bits(rank), u, v} of that closest hit
-    uint32_t* bq_roots;    // [k * bq_cap + item]: mesh-BVH roots, terminated by REF_NONE when fewer than RT_DEFER_ROOTS
+    uint32_t* bq_roots;    // [k * bq_cap + item]: mesh-BVH roots (their count rides in bq_b.w's top 3 bits); [item] == REF_NONE: hole
     uint32_t bq_cap;       // items the queue can hold (rays beyond it are traversed inline)
     uint32_t sh_cap;       // entries sh_queue can hold (holes of the chunked appends included)
     uint32_t* bq_spill;    // GPU: k_bvh's stack entries beyond its short LDS stack, [entry][global lane]
@@ -142,11 +142,10 @@ RT_FN bool defer_bvh(const DScene& S, const Batch& B, uint32_t counter, f3 o, f3
         return false;
     }
     q4 a = {o.x, o.y, o.z, best.t};
-    q4 b = {d.x, d.y, d.z, u2f(dst)};
+    q4 b = {d.x, d.y, d.z, u2f(dst | ((sp - 1u) << 29))};   // dst < 2^29 (checked where the batch is sized); 1 <= sp <= RT_DEFER_ROOTS
     B.bq_a[slot] = a; B.bq_b[slot] = b;
     if (!AO) { q4 c = {u2f(best.prim), u2f(best.rank), best.u, best.v}; B.bq_c[slot] = c; }
     for (uint32_t k = 0; k < sp; ++k) B.bq_roots[(size_t)k * B.bq_cap + slot] = st.p[k * st.stride];
-    if (sp < RT_DEFER_ROOTS) B.bq_roots[(size_t)sp * B.bq_cap + slot] = (uint32_t)REF_NONE;
     return true;
 }
 
@@ -208,10 +207,9 @@ RT_FN bool defer_ao(const DScene& S, const Batch& B, uint32_t counter, bool want
         return false;
     }
     q4 a = {o.x, o.y, o.z, best.t};
-    q4 b = {d.x, d.y, d.z, u2f(dst)};
+    q4 b = {d.x, d.y, d.z, u2f(dst | ((sp - 1u) << 29))};
     B.bq_a[slot] = a; B.bq_b[slot] = b;
     for (uint32_t k = 0; k < sp; ++k) B.bq_roots[(size_t)k * B.bq_cap + slot] = st.p[k * st.stride];
-    if (sp < RT_DEFER_ROOTS) B.bq_roots[(size_t)sp * B.bq_cap + slot] = (uint32_t)REF_NONE;
     return true;
 }
 
@@ -238,14 +236,13 @@ RT_FN void bvh_item(const DScene& S, const Batch& B, uint32_t idx, Stack st, Cou
     Hit best; best.t = a.w; best.prim = H_MISS; best.rank = 0; best.u = 0; best.v = 0;
     if (!AO) { q4 c = B.bq_c[idx]; best.prim = f2u(c.x); best.rank = f2u(c.y); best.u = c.z; best.v = c.w; }
     RayCull rc = make_cull(S, o, d);
-    for (uint32_t k = 0; k < RT_DEFER_ROOTS; ++k) {
-        uint32_t r = B.bq_roots[(size_t)k * B.bq_cap + idx];
-        if (r == REF_NONE) break;
+    const uint32_t nroots = (f2u(b.w) >> 29) + 1u, dst = f2u(b.w) & 0x1FFFFFFFu;
+    if (B.bq_roots[idx] == REF_NONE) return;   // hole
+    for (uint32_t k = 0; k < nroots; ++k) {
         uint32_t sp = 1;
-        st.p[0] = r;
+        st.p[0] = B.bq_roots[(size_t)k * B.bq_cap + idx];
         bvh_drain<STATS, false>(S, o, d, rc, best, st, sp, cnt);
     }
-    uint32_t dst = f2u(b.w);
     if (AO) B.ao_t[dst] = best.t;
     else { q4 r = {best.t, u2f(best.prim), best.u, best.v}; B.hit[dst] = r; }
 }
