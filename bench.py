@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--spp", type=int, default=16)
     ap.add_argument("--mesh-nu", type=int, default=700)
     ap.add_argument("--mesh-nv", type=int, default=360)
+    ap.add_argument("--batch-paths", type=int, default=0, help="paths per wavefront batch (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL over xGMI) or gloo (rehearsal: ranks may share one GPU, slabs staged through the host)")
     ap.add_argument("--cpu-crop", type=int, default=32, help="edge of the centre crop timed on the CPU")
@@ -66,6 +67,7 @@ def main():
     r.upload(flat)
     params = world.params(seed=1)
     params.tile_rank, params.tile_world = rank, world_size
+    params.batch_paths = args.batch_paths
     W, H = args.width, args.height
 
     owned = r.owned_tiles(params, rank, world_size)

@@ -190,10 +190,16 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
         const uint32_t nidle = (uint32_t)__popcll(idle);
         if (!exhausted && (nidle >= RT_REFILL_IDLE)) {
             if (chunk_next >= chunk_end) {
+                // guided self-scheduling: full chunks while plenty of items remain, smaller ones near the
+                // end of the queue so the launch does not end with a few waves holding hundreds of rays
+                const uint32_t rem = chunk_end < n ? n - chunk_end : 0u;
+                uint32_t take = (rem >> 14) << 6;
+                take = take < 64u ? 64u : (take > RT_BVH_CHUNK ? (uint32_t)RT_BVH_CHUNK : take);
+                if (chunk_end == 0) take = RT_BVH_CHUNK;   // first grab: position unknown
                 uint32_t b0 = 0;
-                if (lane == 0) b0 = atomicAdd(next, (uint32_t)RT_BVH_CHUNK);
+                if (lane == 0) b0 = atomicAdd(next, take);
                 b0 = __shfl(b0, 0);
-                chunk_next = b0; chunk_end = b0 + RT_BVH_CHUNK < n ? b0 + RT_BVH_CHUNK : n;
+                chunk_next = b0; chunk_end = b0 + take < n ? b0 + take : n;
                 if (b0 >= n) { exhausted = true; chunk_next = chunk_end = 0; }
             }
             const uint32_t base = chunk_next, lim = chunk_end;
@@ -736,7 +742,7 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
     const bool bounces = s->host.has_bounce_materials;
     const int levels_alloc = bounces ? A.levels : 1;
     const uint64_t per_tile = (uint64_t)RT_TILE * RT_TILE * (uint64_t)A.spp;
-    uint64_t want = p->batch_paths ? p->batch_paths : (4u << 20);
+    uint64_t want = p->batch_paths ? p->batch_paths : (16u << 20);
     uint32_t tiles_per_batch = (uint32_t)(want / per_tile);
     if (tiles_per_batch < 1) tiles_per_batch = 1;
     if (tiles_per_batch > owned && owned > 0) tiles_per_batch = owned;

@@ -158,6 +158,7 @@ RT_FN bool defer_bvh(const DScene& S, const Batch& B, uint32_t counter, f3 o, f3
 struct QCursor { uint32_t next, end; };
 #define RT_QCHUNK 1024u    // BVH work queue (k_ao)
 #define RT_SHCHUNK 256u    // shadow queue (k_prep)
+#define RT_AO_BLOCK 4096u   // slots per block of the AO kernel's blocked stratum-major order (power of two)
 
 template <uint32_t CHUNK>
 RT_FN uint32_t chunk_append(uint32_t* counter, bool want, QCursor& qc, uint32_t* holes, uint32_t hole_value, uint32_t cap)
@@ -370,7 +371,17 @@ RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int dep
     uint32_t dst = 0, sp = 0;
     uint32_t slot = 0, k = 0, p = 0xFFFFFFFFu;
     if (valid) {   // slot = position of the path in this depth's path list; paths without AO rays hold no path id
-        slot = idx % nslots; k = idx / nslots;
+        // blocked stratum-major order: RT_AO_BLOCK consecutive slots x all n*n strata, stratum by
+        // stratum, so the 16 passes over a block's hit records (~70 B each) are served by L2
+        const uint32_t n2b = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
+        const uint32_t nfull = nslots & ~(RT_AO_BLOCK - 1u);
+        if (idx < nfull * n2b) {
+            const uint32_t b = idx / (RT_AO_BLOCK * n2b), r = idx % (RT_AO_BLOCK * n2b);
+            k = r / RT_AO_BLOCK; slot = b * RT_AO_BLOCK + (r & (RT_AO_BLOCK - 1u));
+        } else {
+            const uint32_t r = idx - nfull * n2b, tail = nslots - nfull;
+            k = r / tail; slot = nfull + r % tail;
+        }
         p = B.ao_queue[slot];
         valid = p != 0xFFFFFFFFu;
     }
