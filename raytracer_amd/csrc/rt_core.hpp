@@ -611,8 +611,17 @@ RT_FN void sincos_f64(double x, double& sn, double& cs)
     if ((n + 1) & 2) cs = -cs;
 }
 
-RT_FN void ao_ray(const rt_ambient& A, f3 P, f3 N, uint32_t seed, uint32_t pixel, uint32_t sample,
-                  uint32_t ao_call, uint32_t k, f3& o, f3& dir)
+// The part of the AO ray that is the same for all n*n rays of a hit (computed once, by k_prep):
+// rotationMatToSpace's basis and the offset origin.
+RT_FN void ao_frame(f3 P, f3 N, f3& o, f3& u, f3& w)
+{
+    w = normalize(N);
+    u = normalize(cross(w, F3(0.053f, 1.0f, 0.0332f)));
+    o = P + N * 0.01f;
+}
+
+// Direction of AO ray k (stratum x = k / n, y = k % n) in the frame (u, w)
+RT_FN f3 ao_dir(const rt_ambient& A, f3 u, f3 w, uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t ao_call, uint32_t k)
 {
     unsigned n = (unsigned)A.occlusion_samples;
     uint32_t x = k / n, y = k % n;
@@ -627,12 +636,9 @@ RT_FN void ao_ray(const rt_ambient& A, f3 P, f3 N, uint32_t seed, uint32_t pixel
     double sn, cs;
     sincos_f64((double)phi, sn, cs);
     f3 h = F3((float)cs * r, sampleX, (float)sn * r);
-    f3 w = normalize(N);
-    f3 u = normalize(cross(w, F3(0.053f, 1.0f, 0.0332f)));
     f3 v = cross(w, u);
     f3 rr = (u * h.x + w * h.y) + (v * h.z + F3(0.0f, 0.0f, 0.0f));
-    dir = normalize(rr);
-    o = P + N * 0.01f;
+    return normalize(rr);
 }
 
 // Transparency::refraction (main.cpp:1566-1592)

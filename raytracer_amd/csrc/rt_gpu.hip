@@ -466,7 +466,7 @@ size_t carve_batch(Batch& B, char* base, uint32_t P, int levels, uint32_t nl, ui
     B.hit = (q4*)take(sizeof(q4) * P);
     B.nrm = (q4*)take(sizeof(q4) * P);
     B.pstate = (uint32_t*)take(4ull * P);
-    B.ao_queue = (uint32_t*)take(4ull * P);
+    B.ao_o = (q4*)take(sizeof(q4) * P); B.ao_u = (q4*)take(sizeof(q4) * P); B.ao_w = (q4*)take(sizeof(q4) * P);
     B.ao_slot = (uint32_t*)take(4ull * P);
     // worst case of the chunked appends: <= 63 holes per RT_SHCHUNK-slot chunk + one open chunk per wave of k_prep
     B.sh_cap = (uint32_t)std::min<size_t>((size_t)P * nl * RT_SHCHUNK / (RT_SHCHUNK - 63) + RT_SHCHUNK + (size_t)RT_MAX_GRID * (RT_BLOCK / 64) * RT_SHCHUNK, 0xFFFF0000u);

@@ -32,8 +32,10 @@ struct Batch {
     q4* nrm;               // {normal, bits(material)}
     uint32_t* pstate;      // bits 0..7: Ambient::L evaluations so far; bits 8..15: index of the current one
     uint32_t* queue[2];    // paths alive at depth d (d >= 1), ping-pong
-    uint32_t* ao_queue;    // paths whose ambient term needs occlusion rays at this depth
-    uint32_t* ao_slot;     // per path: its position in ao_queue, 0xFFFFFFFF = none
+    // AO work is positional: slot = position of the path in this depth's path list.  Per slot, written by
+    // k_prep: {origin, bits(pixel key)} {u, bits(sample)} {w, bits(AO call index), 0xFFFFFFFF = no AO rays}
+    q4* ao_o; q4* ao_u; q4* ao_w;
+    uint32_t* ao_slot;     // per path: its slot, 0xFFFFFFFF = none
     uint32_t* sh_queue;    // p * num_lights + light
     float* ao_t;           // [slot * n*n + k]  closest distance (occlusion_dist when nothing was hit)
     float* sh_res;         // [p * num_lights + light]
@@ -252,7 +254,7 @@ RT_FN void bvh_item(const DScene& S, const Batch& B, uint32_t idx, Stack st, Cou
 // the hit point and shading normal.  The AO "queue" is positional: slot = idx, no append.
 RT_FN bool prep_body(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, uint32_t& p_out, f3& P_out, f3& N_out)
 {
-    B.ao_queue[idx] = 0xFFFFFFFFu;
+    { q4 none = {0.0f, 0.0f, 0.0f, u2f(0xFFFFFFFFu)}; B.ao_w[idx] = none; }
     uint32_t p = item_path(A, B, depth, idx);
     PathPix px = path_of(A, p);
     p_out = p;
@@ -291,7 +293,10 @@ RT_FN bool prep_body(const DScene& S, const RenderArgs& A, const Batch& B, int d
         B.pstate[p] = ps;
         if (M.ka != 0.0f) {   // ka == 0 multiplies the (finite) occlusion factor away: no rays needed
             slot = idx;
-            B.ao_queue[slot] = p;
+            f3 ao, au, aw;
+            ao_frame(P, sf.normal, ao, au, aw);
+            q4 r0 = {ao.x, ao.y, ao.z, u2f(px.key)}, r1 = {au.x, au.y, au.z, u2f(px.j)}, r2 = {aw.x, aw.y, aw.z, u2f(a)};
+            B.ao_o[slot] = r0; B.ao_u[slot] = r1; B.ao_w[slot] = r2;
         }
     }
     B.ao_slot[p] = slot;
@@ -369,7 +374,7 @@ RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int dep
     f3 o = F3(0, 0, 0), dir = F3(0, 0, 1);
     Hit h = {}; float sh;
     uint32_t dst = 0, sp = 0;
-    uint32_t slot = 0, k = 0, p = 0xFFFFFFFFu;
+    uint32_t slot = 0, k = 0;
     if (valid) {   // slot = position of the path in this depth's path list; paths without AO rays hold no path id
         // blocked stratum-major order: RT_AO_BLOCK consecutive slots x all n*n strata, stratum by
         // stratum, so the 16 passes over a block's hit records (~70 B each) are served by L2
@@ -382,20 +387,19 @@ RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int dep
             const uint32_t r = idx - nfull * n2b, tail = nslots - nfull;
             k = r / tail; slot = nfull + r % tail;
         }
-        p = B.ao_queue[slot];
-        valid = p != 0xFFFFFFFFu;
     }
     if (valid) {
-        cnt.rays++;
-        uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
-        PathPix px = path_of(A, p);
-        q4 o4 = B.ray_o[depth & 1][p], d4 = B.ray_d[depth & 1][p];
-        f3 P = xyz(o4) + xyz(d4) * B.hit[p].x;
-        f3 N = xyz(B.nrm[p]);
-        uint32_t a = (B.pstate[p] >> 8) & 0xFFu;
-        ao_ray(S.ambient, P, N, A.seed, px.key, px.j, a, k, o, dir);
-        dst = slot * n2 + k;
-        sp = trace<0, STATS, true>(S, o, dir, S.ambient.occlusion_dist, h, sh, st, cnt);
+        const q4 rw = B.ao_w[slot];
+        valid = f2u(rw.w) != 0xFFFFFFFFu;
+        if (valid) {
+            const q4 ro = B.ao_o[slot], ru = B.ao_u[slot];
+            cnt.rays++;
+            o = xyz(ro);
+            dir = ao_dir(S.ambient, xyz(ru), xyz(rw), A.seed, f2u(ro.w), f2u(ru.w), f2u(rw.w), k);
+            uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
+            dst = slot * n2 + k;
+            sp = trace<0, STATS, true>(S, o, dir, S.ambient.occlusion_dist, h, sh, st, cnt);
+        }
     }
     if (defer_ao<STATS>(S, B, C_BQA + depth, sp > 0, o, dir, h, dst, st, sp, cnt, qc)) return;
     if (valid) B.ao_t[dst] = h.t;   // stays occlusion_dist when nothing closer was found

@@ -111,18 +111,19 @@ int emul_render(const rt_scene_desc* d, const rt_camera* cam, const rt_params* p
     Batch& B = be.B;
     B.P = P;
     std::vector<q4> ro0(P), ro1(P), rd0(P), rd1(P), hit(P), nrm(P), lvl((size_t)P * A.levels);
-    std::vector<uint32_t> pstate(P), q0(P), q1(P), aoq(P), aos(P), shq((size_t)P * nl), counters(C_TOTAL);
+    std::vector<uint32_t> pstate(P), q0(P), q1(P), aos(P), shq((size_t)P * nl), counters(C_TOTAL);
     std::vector<float> aot((size_t)P * (n2 ? n2 : 1)), shr((size_t)P * nl), lph((size_t)P * A.levels * (nl > 1 ? nl - 1 : 1));
     std::vector<uint8_t> kind((size_t)P * A.levels);
     std::vector<unsigned long long> stats(ST_TOTAL, 0);
     // a deliberately small queue so the inline fallback of defer_bvh is exercised too
+    std::vector<q4> aoo(P), aou(P), aow(P);
     B.bq_cap = P * (n2 ? n2 : 1) / 3 + 1;
     B.sh_cap = (uint32_t)shq.size();
     std::vector<q4> bqa(B.bq_cap), bqb(B.bq_cap), bqc(B.bq_cap); std::vector<uint32_t> bqr((size_t)B.bq_cap * RT_DEFER_ROOTS);
     B.bq_a = bqa.data(); B.bq_b = bqb.data(); B.bq_c = bqc.data(); B.bq_roots = bqr.data();
     B.ray_o[0] = ro0.data(); B.ray_o[1] = ro1.data(); B.ray_d[0] = rd0.data(); B.ray_d[1] = rd1.data();
     B.hit = hit.data(); B.nrm = nrm.data(); B.pstate = pstate.data(); B.queue[0] = q0.data(); B.queue[1] = q1.data();
-    B.ao_queue = aoq.data(); B.ao_slot = aos.data(); B.sh_queue = shq.data(); B.ao_t = aot.data(); B.sh_res = shr.data();
+    B.ao_o = aoo.data(); B.ao_u = aou.data(); B.ao_w = aow.data(); B.ao_slot = aos.data(); B.sh_queue = shq.data(); B.ao_t = aot.data(); B.sh_res = shr.data();
     B.lvl = lvl.data(); B.lvl_ph = lph.data(); B.lvl_kind = kind.data(); B.counters = counters.data(); B.stats = stats.data();
     render_frame(be, A, owned, tiles_per_batch, H.has_bounce_materials);
     if (out_counts) {
