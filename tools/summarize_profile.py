@@ -38,7 +38,7 @@ if st:
             open(os.path.join(P, f"{tag}_bench_under_rocprof.json"), "w").write(lines[-1])
 
 rows = []
-for sub in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
+for sub in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq", "pmc_sq2", "pmc_ta"):
     f = glob.glob(os.path.join(G, f"{tag}_{sub}", "*", "*_counter_collection.csv"))
     if not f:
         continue
