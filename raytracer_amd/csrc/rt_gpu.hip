@@ -142,6 +142,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B
 #define RT_BVH_CHUNK 512
 #define RT_REFILL_IDLE 16    // refill once this many lanes hold no ray
 #define RT_PEND 4            // parked leaves per lane
+#define RT_NODE_REPS 2       // steps of one kind per vote (see the vote below)
+#define RT_TRI_REPS 3
 #define RT_LDS_STACK 12      // stack entries per lane kept in LDS; deeper ones spill to global memory (rare)
 
 template <bool AO, bool STATS>
@@ -233,58 +235,72 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
             if (__ballot(active) == 0ull && (exhausted || n == 0)) break;
             continue;   // only finished rays (retired at the top) or an empty refill: go round again
         }
+        // The winner of the vote is repeated (up to RT_*_REPS steps) while at least 3/4 of its voters
+        // are ready again: the retire / refill / vote code above is a third of an iteration.
         if (n_node > n_tri) {
-            if (can_node) {
-                uint32_t c0 = REF_NONE, c1 = REF_NONE;
-                if (!(cur & REF_LEAF)) {
-                    const q4* np = S.nodes + (size_t)cur * 2;
-                    const q4 n0 = np[0], n1 = np[1];
-                    if (STATS) cnt.nodes++;
-                    uint32_t r0, r1;
-                    float t0, t1;
-                    bool h0, h1;
-                    node_test(rc, n0, n1, best.t, h0, h1, t0, t1, r0, r1);
-                    const bool swap = h0 && h1 && t1 < t0;
-                    c0 = h0 ? r0 : (uint32_t)REF_NONE; c1 = h1 ? r1 : (uint32_t)REF_NONE;
-                    if (swap) { const uint32_t x = c0; c0 = c1; c1 = x; }
-                } else {
-                    c0 = cur;   // a leaf that arrived as a root or waited for room
+            bool cn = can_node;
+            for (int rep = 0;; ++rep) {
+                if (cn) {
+                    uint32_t c0 = REF_NONE, c1 = REF_NONE;
+                    if (!(cur & REF_LEAF)) {
+                        const q4* np = S.nodes + (size_t)cur * 2;
+                        const q4 n0 = np[0], n1 = np[1];
+                        if (STATS) cnt.nodes++;
+                        uint32_t r0, r1;
+                        float t0, t1;
+                        bool h0, h1;
+                        node_test(rc, n0, n1, best.t, h0, h1, t0, t1, r0, r1);
+                        const bool swap = h0 && h1 && t1 < t0;
+                        c0 = h0 ? r0 : (uint32_t)REF_NONE; c1 = h1 ? r1 : (uint32_t)REF_NONE;
+                        if (swap) { const uint32_t x = c0; c0 = c1; c1 = x; }
+                    } else {
+                        c0 = cur;   // a leaf that arrived as a root or waited for room
+                    }
+                    // leaves are parked for the triangle steps; inner nodes continue the descent
+                    if (c0 != REF_NONE && (c0 & REF_LEAF) && npend < RT_PEND) { pend[(npend++) * RT_BLOCK] = c0; c0 = REF_NONE; }
+                    if (c1 != REF_NONE && (c1 & REF_LEAF) && npend < RT_PEND) { pend[(npend++) * RT_BLOCK] = c1; c1 = REF_NONE; }
+                    if (c0 == REF_NONE) { c0 = c1; c1 = REF_NONE; }
+                    if (c1 != REF_NONE) push(sp, c1);
+                    cur = c0;
+                    while (cur == REF_NONE && sp > 0) {   // pop; leaves that come off the stack are parked right away
+                        const uint32_t x = pop(sp);
+                        if ((x & REF_LEAF) && npend < RT_PEND) pend[(npend++) * RT_BLOCK] = x;
+                        else cur = x;
+                    }
                 }
-                // leaves are parked for the triangle steps; inner nodes continue the descent
-                if (c0 != REF_NONE && (c0 & REF_LEAF) && npend < RT_PEND) { pend[(npend++) * RT_BLOCK] = c0; c0 = REF_NONE; }
-                if (c1 != REF_NONE && (c1 & REF_LEAF) && npend < RT_PEND) { pend[(npend++) * RT_BLOCK] = c1; c1 = REF_NONE; }
-                if (c0 == REF_NONE) { c0 = c1; c1 = REF_NONE; }
-                if (c1 != REF_NONE) push(sp, c1);
-                cur = c0;
-                while (cur == REF_NONE && sp > 0) {   // pop; leaves that come off the stack are parked right away
-                    const uint32_t x = pop(sp);
-                    if ((x & REF_LEAF) && npend < RT_PEND) pend[(npend++) * RT_BLOCK] = x;
-                    else cur = x;
-                }
+                if (rep == RT_NODE_REPS - 1) break;
+                cn = active && cur != REF_NONE && (!(cur & REF_LEAF) || npend < RT_PEND);
+                if ((uint32_t)__popcll(__ballot(cn)) * 4u < n_node * 3u) break;
             }
         } else {
-            if (can_tri) {
-                if (tri_left == 0) {
-                    const uint32_t ref = pend[(--npend) * RT_BLOCK];
-                    tri_next = ref & 0x0FFFFFFFu; tri_left = ((ref >> 28) & 7u) + 1u;
+            bool ct = can_tri;
+            for (int rep = 0;; ++rep) {
+                if (ct) {
+                    if (tri_left == 0) {
+                        const uint32_t ref = pend[(--npend) * RT_BLOCK];
+                        tri_next = ref & 0x0FFFFFFFu; tri_left = ((ref >> 28) & 7u) + 1u;
+                    }
+                    const q4* T = S.tris + (size_t)tri_next * 3;
+                    const q4 a = T[0], b = T[1], e = T[2];
+                    if (STATS) cnt.tris++;
+                    // Triangle::intersectRay (reference main.cpp:713-739), branch-free
+                    const f3 v0v1 = xyz(b), v0v2 = xyz(e);
+                    const f3 pvec = cross(d, v0v2);
+                    const float det = dot(v0v1, pvec);
+                    const float invDet = 1.0f / det;
+                    const f3 tvec = o - xyz(a);
+                    const float u = dot(tvec, pvec) * invDet;
+                    const f3 qvec = cross(tvec, v0v1);
+                    const float v = dot(d, qvec) * invDet;
+                    const float t = dot(v0v2, qvec) * invDet;
+                    const bool ok = !(det < 0.000001f) && !(u < 0 || u > 1) && !(v < 0 || u + v > 1);
+                    const uint32_t rank = f2u(e.w);
+                    if (ok && closer(t, rank, best)) { best.t = t; best.prim = H_TRI | tri_next; best.u = u; best.v = v; best.rank = rank; }
+                    tri_next++; tri_left--;
                 }
-                const q4* T = S.tris + (size_t)tri_next * 3;
-                const q4 a = T[0], b = T[1], e = T[2];
-                if (STATS) cnt.tris++;
-                // Triangle::intersectRay (reference main.cpp:713-739), branch-free
-                const f3 v0v1 = xyz(b), v0v2 = xyz(e);
-                const f3 pvec = cross(d, v0v2);
-                const float det = dot(v0v1, pvec);
-                const float invDet = 1.0f / det;
-                const f3 tvec = o - xyz(a);
-                const float u = dot(tvec, pvec) * invDet;
-                const f3 qvec = cross(tvec, v0v1);
-                const float v = dot(d, qvec) * invDet;
-                const float t = dot(v0v2, qvec) * invDet;
-                const bool ok = !(det < 0.000001f) && !(u < 0 || u > 1) && !(v < 0 || u + v > 1);
-                const uint32_t rank = f2u(e.w);
-                if (ok && closer(t, rank, best)) { best.t = t; best.prim = H_TRI | tri_next; best.u = u; best.v = v; best.rank = rank; }
-                tri_next++; tri_left--;
+                if (rep == RT_TRI_REPS - 1) break;
+                ct = active && (tri_left > 0 || npend > 0);
+                if ((uint32_t)__popcll(__ballot(ct)) * 4u < n_tri * 3u) break;
             }
         }
     }
