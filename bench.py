@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--spp", type=int, default=16)
     ap.add_argument("--mesh-nu", type=int, default=700)
     ap.add_argument("--mesh-nv", type=int, default=360)
+    ap.add_argument("--lib", default=None, help="alternative librt_amd.so (kernel tuning builds)")
     ap.add_argument("--batch-paths", type=int, default=0, help="paths per wavefront batch (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL over xGMI) or gloo (rehearsal: ranks may share one GPU, slabs staged through the host)")
@@ -63,7 +64,7 @@ def main():
     world = scenes.config3_scene(args.width, args.height, args.spp, args.mesh_nu, args.mesh_nv)
     flat = world.flatten()
     ntri = int(flat.arrays["triangles"].shape[0])
-    r = Renderer(gpu_index)
+    r = Renderer(gpu_index, args.lib)
     r.upload(flat)
     params = world.params(seed=1)
     params.tile_rank, params.tile_world = rank, world_size

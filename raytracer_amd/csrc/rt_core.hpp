@@ -244,7 +244,8 @@ RT_FN RayCull make_cull(const DScene& S, f3 o, f3 d)
     float dx = fabsf(d.x) > 1e-20f ? d.x : (d.x < 0 ? -1e-20f : 1e-20f);
     float dy = fabsf(d.y) > 1e-20f ? d.y : (d.y < 0 ? -1e-20f : 1e-20f);
     float dz = fabsf(d.z) > 1e-20f ? d.z : (d.z < 0 ? -1e-20f : 1e-20f);
-    float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    // approximate reciprocals are enough: their 1-ulp error is inside cull_box's relative slack
+    float ix = approx_rcp(dx), iy = approx_rcp(dy), iz = approx_rcp(dz);
     float bx = S.qbase.x - o.x, by = S.qbase.y - o.y, bz = S.qbase.z - o.z;
     c.sx = S.qscale.x * ix; c.sy = S.qscale.y * iy; c.sz = S.qscale.z * iz;
     c.lx = (bx - pad) * ix; c.hx = (bx + pad) * ix;

@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B
     // wave-uniform trip count: every lane of a wave takes part in the queue cursor's ballots
     for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
         const uint32_t i = base + threadIdx.x;
-        ao_item<STATS>(S, A, B, depth, i, nslots, i < n, st, cnt, qc);
+        ao_item<STATS>(S, A, B, depth, base, threadIdx.x, nslots, i < n, st, cnt, qc);
     }
     close_cursor(qc, B.bq_roots, (uint32_t)REF_NONE, B.bq_cap);
     flush_counters<STATS>(cnt, B.stats, 2);
@@ -139,12 +139,28 @@ __global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B
 //    tri_t(); only the early returns are folded into one predicate).
 // Results are identical to bvh_item()/bvh_drain() (rt_pipeline.hpp / rt_core.hpp), which the CPU
 // emulation runs: the closest hit does not depend on visiting order (ties resolved by rank).
+#ifndef RT_BVH_CHUNK
 #define RT_BVH_CHUNK 512
+#endif
+#ifndef RT_REFILL_IDLE
 #define RT_REFILL_IDLE 16    // refill once this many lanes hold no ray
-#define RT_PEND 4            // parked leaves per lane
-#define RT_NODE_REPS 2       // steps of one kind per vote (see the vote below)
-#define RT_TRI_REPS 3
+#endif
+#ifndef RT_PEND
+#define RT_PEND 3            // parked leaves per lane
+#endif
+#ifndef RT_NODE_REPS
+#define RT_NODE_REPS 3       // steps of one kind per vote (see the vote below)
+#endif
+#ifndef RT_TRI_REPS
+#define RT_TRI_REPS 4
+#endif
+#ifndef RT_REP_NUM
+#define RT_REP_NUM 1         // repeat while RT_REP_NUM/RT_REP_DEN of the voters are ready again
+#define RT_REP_DEN 2
+#endif
+#ifndef RT_LDS_STACK
 #define RT_LDS_STACK 12      // stack entries per lane kept in LDS; deeper ones spill to global memory (rare)
+#endif
 
 template <bool AO, bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter, int next_counter)
@@ -235,7 +251,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
             if (__ballot(active) == 0ull && (exhausted || n == 0)) break;
             continue;   // only finished rays (retired at the top) or an empty refill: go round again
         }
-        // The winner of the vote is repeated (up to RT_*_REPS steps) while at least 3/4 of its voters
+        // The winner of the vote is repeated (up to RT_*_REPS steps) while RT_REP_NUM/RT_REP_DEN of its voters
         // are ready again: the retire / refill / vote code above is a third of an iteration.
         if (n_node > n_tri) {
             bool cn = can_node;
@@ -270,7 +286,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
                 }
                 if (rep == RT_NODE_REPS - 1) break;
                 cn = active && cur != REF_NONE && (!(cur & REF_LEAF) || npend < RT_PEND);
-                if ((uint32_t)__popcll(__ballot(cn)) * 4u < n_node * 3u) break;
+                if ((uint32_t)__popcll(__ballot(cn)) * RT_REP_DEN < n_node * RT_REP_NUM) break;
             }
         } else {
             bool ct = can_tri;
@@ -300,7 +316,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
                 }
                 if (rep == RT_TRI_REPS - 1) break;
                 ct = active && (tri_left > 0 || npend > 0);
-                if ((uint32_t)__popcll(__ballot(ct)) * 4u < n_tri * 3u) break;
+                if ((uint32_t)__popcll(__ballot(ct)) * RT_REP_DEN < n_tri * RT_REP_NUM) break;
             }
         }
     }

@@ -366,7 +366,7 @@ RT_FN void shadow_item(const DScene& S, const RenderArgs& A, const Batch& B, int
 }
 
 template <bool STATS>
-RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, uint32_t nslots, bool valid, Stack st,
+RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t base, uint32_t off, uint32_t nslots, bool valid, Stack st,
                    Counters& cnt, QCursor& qc)
 {
     // stratum-major order: a wave traces the same stratum (x,y) of 64 neighbouring hits, whose
@@ -378,13 +378,15 @@ RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int dep
     if (valid) {   // slot = position of the path in this depth's path list; paths without AO rays hold no path id
         // blocked stratum-major order: RT_AO_BLOCK consecutive slots x all n*n strata, stratum by
         // stratum, so the 16 passes over a block's hit records (~70 B each) are served by L2
+        // item = base + off with base a multiple of 256 that is the same for the whole workgroup (GPU) and
+        // off < 256: block and stratum come from `base` alone, i.e. from scalar registers
         const uint32_t n2b = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
         const uint32_t nfull = nslots & ~(RT_AO_BLOCK - 1u);
-        if (idx < nfull * n2b) {
-            const uint32_t b = idx / (RT_AO_BLOCK * n2b), r = idx % (RT_AO_BLOCK * n2b);
-            k = r / RT_AO_BLOCK; slot = b * RT_AO_BLOCK + (r & (RT_AO_BLOCK - 1u));
+        if (base < nfull * n2b) {
+            const uint32_t b = base / (RT_AO_BLOCK * n2b), r = base % (RT_AO_BLOCK * n2b);
+            k = r / RT_AO_BLOCK; slot = b * RT_AO_BLOCK + (r & (RT_AO_BLOCK - 1u)) + off;
         } else {
-            const uint32_t r = idx - nfull * n2b, tail = nslots - nfull;
+            const uint32_t r = base + off - nfull * n2b, tail = nslots - nfull;
             k = r / tail; slot = nfull + r % tail;
         }
     }

@@ -44,7 +44,7 @@ struct LoopBackend {
         uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
         QCursor qc{0, 0};
         const uint32_t nslots = count(d, fixed);
-        for (uint32_t i = 0, n = nslots * n2; i < n; ++i) ao_item<true>(S, A, B, d, i, nslots, true, st, cnt[2], qc);
+        for (uint32_t i = 0, n = nslots * n2; i < n; ++i) ao_item<true>(S, A, B, d, i & ~255u, i & 255u, nslots, true, st, cnt[2], qc);
     }
     void shade(const RenderArgs& A, int d, uint32_t fixed) { for (uint32_t i = 0, n = count(d, fixed); i < n; ++i) shade_item(S, A, B, d, i); }
     void resolve(const RenderArgs& A, uint32_t n) {
