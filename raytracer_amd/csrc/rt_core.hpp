@@ -163,6 +163,28 @@ RT_FN bool gate_maybe(const float* mn, const float* mx, f3 o, const RayGate& r)
     return (n - slack <= f + slack) && (f + slack >= 0.0f);
 }
 
+// Conservative ACCEPT for the same gate.  box_intersects() is true as soon as ONE face test passes:
+// |d_a| >= 1e-5, t = (c - o_a)/d_a in [0, FLT_MAX) and the point o + d*t strictly inside the face's
+// rectangle on the other two axes.  Take the exit planes (c = mx_a for d_a > 0, else mn_a) of the axes
+// with |d_a| safely above 1e-5, the smallest approximate parameter t among them, and the point there:
+// if t is safely positive and the point is inside the rectangle by the margin pad (>= 6x the
+// rounding of either evaluation, see gate_maybe), that face's exact test passes too.  Anything
+// else (edge exits, tiny |d_a|, origin on a plane) is left to the exact test.
+RT_FN bool gate_surely(const float* mn, const float* mx, f3 o, f3 d, const RayGate& r)
+{
+    const float tx = fabsf(d.x) > 1.0001e-5f ? ((d.x > 0 ? mx[0] : mn[0]) - o.x) * r.ix : FLT_MAX;
+    const float ty = fabsf(d.y) > 1.0001e-5f ? ((d.y > 0 ? mx[1] : mn[1]) - o.y) * r.iy : FLT_MAX;
+    const float tz = fabsf(d.z) > 1.0001e-5f ? ((d.z > 0 ? mx[2] : mn[2]) - o.z) * r.iz : FLT_MAX;
+    const float t = fminf(fminf(tx, ty), tz);
+    if (!(t > 1e-20f && t < 1e30f)) return false;
+    const float hx = o.x + d.x * t, hy = o.y + d.y * t, hz = o.z + d.z * t;
+    const bool inx = hx > mn[0] + r.pad && hx < mx[0] - r.pad;
+    const bool iny = hy > mn[1] + r.pad && hy < mx[1] - r.pad;
+    const bool inz = hz > mn[2] + r.pad && hz < mx[2] - r.pad;
+    const bool sx = t == tx, sy = !sx && t == ty, sz = !sx && !sy;   // exactly one axis is the face's own
+    return (sx || inx) && (sy || iny) && (sz || inz);
+}
+
 // One face of BoundingVolumeBox::intersects (main.cpp:245-296).  For an axis-aligned unit normal
 // the reference's dot products reduce exactly to (c - o[a]) / d[a].
 RT_FN bool box_face(int axis, float c, const float* mn, const float* mx, f3 o, f3 d)
@@ -395,7 +417,7 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
             break;
         case G_GATED:
             if (STATS) cnt.gates++;
-            i = ((g.kind & G_SAME_BOX) || (gate_maybe(g.mn, g.mx, o, rg) && box_intersects(g.mn, g.mx, o, d))) ? i + 1 : g.skip;
+            i = ((g.kind & G_SAME_BOX) || (gate_maybe(g.mn, g.mx, o, rg) && (gate_surely(g.mn, g.mx, o, d, rg) || box_intersects(g.mn, g.mx, o, d)))) ? i + 1 : g.skip;
             break;
         case G_PLANE: {
             float t;
@@ -426,7 +448,7 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
         }
         default: { // G_MESH: gate, then defer its triangle BVH to the shared drain loop
             if (STATS) cnt.gates++;
-            if ((g.kind & G_SAME_BOX) || (gate_maybe(g.mn, g.mx, o, rg) && box_intersects(g.mn, g.mx, o, d))) {
+            if ((g.kind & G_SAME_BOX) || (gate_maybe(g.mn, g.mx, o, rg) && (gate_surely(g.mn, g.mx, o, d, rg) || box_intersects(g.mn, g.mx, o, d)))) {
                 st.p[(sp++) * st.stride] = g.a;
                 if (sp >= (DEFER ? RT_DEFER_ROOTS : RT_PENDING_MAX)) {
                     const RayCull rc = make_cull(S, o, d);

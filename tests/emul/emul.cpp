@@ -164,4 +164,55 @@ int emul_bvh_dump(const rt_scene_desc* d, uint32_t which, float* out, int cap_no
     return n;
 }
 
+// Soundness of the conservative gate classification (rt_core.hpp gate_maybe / gate_surely) against the
+// exact reference test, on random and adversarial (edge / corner grazing, tiny direction components,
+// origins on box planes) rays.  out = {tested, maybe_false, surely_true, ambiguous, violations}
+int emul_gate_check(uint32_t n, uint32_t seed, double* out)
+{
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 12345;
+    auto rnd = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (double)((s >> 11) & ((1ull << 53) - 1)) / (double)(1ull << 53); };
+    double cnt[5] = {0, 0, 0, 0, 0};
+    const float cull_pad = 1.0f / 262144.0f;
+    for (uint32_t it = 0; it < n; ++it) {
+        float mn[3], mx[3];
+        float ext = 1.0f;
+        for (int a = 0; a < 3; ++a) {
+            float c = (float)((rnd() - 0.5) * 2000.0), h = (float)(rnd() * rnd() * 600.0);
+            if ((it & 63) == 7 && a == (int)(it >> 6) % 3) h = 0.0f;   // flat boxes
+            mn[a] = c - h; mx[a] = c + h;
+            ext = fmaxf(ext, fmaxf(fabsf(mn[a]), fabsf(mx[a])));
+        }
+        f3 o, d;
+        const int mode = it % 8;
+        o = F3((float)((rnd() - 0.5) * 3000.0), (float)((rnd() - 0.5) * 3000.0), (float)((rnd() - 0.5) * 3000.0));
+        if (mode == 1) { o.x = mn[0] + (float)rnd() * (mx[0] - mn[0]); o.y = mn[1] + (float)rnd() * (mx[1] - mn[1]); o.z = mn[2] + (float)rnd() * (mx[2] - mn[2]); }   // inside
+        if (mode == 2) o.y = (it & 8) ? mn[1] : mx[1];   // on a plane
+        // aim at a point of the box: interior, face, edge or corner
+        f3 tgt;
+        float* tp = &tgt.x;
+        for (int a = 0; a < 3; ++a) {
+            double u = rnd();
+            if (mode >= 3 && mode <= 5 && a != (int)(it >> 3) % 3) u = (rnd() < 0.5) ? 0.0 : 1.0;   // edges
+            if (mode == 6) u = (rnd() < 0.5) ? 0.0 : 1.0;                                          // corners
+            tp[a] = mn[a] + (float)u * (mx[a] - mn[a]);
+            if (mode == 5) tp[a] += (float)((rnd() - 0.5) * 1e-3);
+        }
+        d = tgt - o;
+        if (mode == 7) { d = F3((float)(rnd() - 0.5), (float)(rnd() - 0.5), (float)(rnd() - 0.5)); float* dp = &d.x; dp[it % 3] = (float)((rnd() - 0.5) * 4e-5); }
+        if (dot(d, d) == 0.0f) continue;
+        d = normalize(d);
+        if ((it & 3) == 3) d = d * -1.0f;
+        const RayGate rg = make_gate(cull_pad, ext, o, d);
+        const bool exact = box_intersects(mn, mx, o, d);
+        const bool maybe = gate_maybe(mn, mx, o, rg);
+        const bool surely = maybe && gate_surely(mn, mx, o, d, rg);
+        cnt[0]++;
+        if (!maybe) { cnt[1]++; if (exact) cnt[4]++; }
+        else if (surely) { cnt[2]++; if (!exact) cnt[4]++; }
+        else cnt[3]++;
+    }
+    for (int k = 0; k < 5; ++k) out[k] = cnt[k];
+    return 0;
+}
+
 } // extern "C"

@@ -103,3 +103,19 @@ def test_tile_split_matches_full_frame(emul):
         part, _, _, _ = emul.render(flat, world.camera, q)
         acc += part
     assert util.bits_equal(acc, full)
+
+
+def test_gate_classification_is_sound(emul):
+    """gate_maybe == False must imply the reference box test fails, gate_surely == True that it
+    passes (rt_core.hpp); 4 M random + adversarial rays (edges, corners, planes, tiny components)."""
+    import ctypes as C
+    import numpy as np
+    lib = emul.lib
+    lib.emul_gate_check.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
+    out = np.zeros(5, np.float64)
+    for seed in (1, 2):
+        assert lib.emul_gate_check(2_000_000, seed, out.ctypes.data) == 0
+        tested, no, yes, amb, bad = out
+        assert bad == 0, out
+        assert no > 0.1 * tested and yes > 0.1 * tested   # both shortcuts are exercised
+        assert amb < 0.35 * tested                        # the adversarial modes are ~3/8 of the cases
