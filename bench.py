@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--batch-paths", type=int, default=0, help="paths per wavefront batch (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL over xGMI) or gloo (rehearsal: ranks may share one GPU, slabs staged through the host)")
-    ap.add_argument("--cpu-crop", type=int, default=32, help="edge of the centre crop timed on the CPU")
+    ap.add_argument("--cpu-crop", type=int, default=96, help="edge of the centre crop timed on the CPU")
     args = ap.parse_args()
 
     import numpy as np
