@@ -143,16 +143,16 @@ __global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B
 #define RT_BVH_CHUNK 512
 #endif
 #ifndef RT_REFILL_IDLE
-#define RT_REFILL_IDLE 16    // refill once this many lanes hold no ray
+#define RT_REFILL_IDLE 32    // refill once this many lanes hold no ray
 #endif
 #ifndef RT_PEND
 #define RT_PEND 3            // parked leaves per lane
 #endif
 #ifndef RT_NODE_REPS
-#define RT_NODE_REPS 3       // steps of one kind per vote (see the vote below)
+#define RT_NODE_REPS 4       // steps of one kind per vote (see the vote below)
 #endif
 #ifndef RT_TRI_REPS
-#define RT_TRI_REPS 4
+#define RT_TRI_REPS 6
 #endif
 #ifndef RT_REP_NUM
 #define RT_REP_NUM 1         // repeat while RT_REP_NUM/RT_REP_DEN of the voters are ready again
