@@ -100,6 +100,7 @@ int main(int argc, char** argv)
             threadPool.startJob([=, &camera, &world] { raytrace(beginY, endY, beginX, endX, camera, world); });
         }
     threadPool.waitDone();
+    std::cout << "tile jobs: " << gridN * gridN << ", GPU launches: " << threadPool.launches() << std::endl;
     saveToFile(out, world->width, world->height, world->image);
     std::cout << "Running time is " << timer.elapsed() << std::endl;
     return 0;

@@ -232,6 +232,13 @@ int rt_unpack_tiles(rt_ctx* ctx, const float* d_slab, const rt_params* p, int ra
 /* Resolve step of saveToFile (main.cpp:1842-1850): uchar(pixel*255), truncating, on device. */
 int rt_quantize_rgb8(rt_ctx* ctx, const float* d_rgb, size_t num_pixels, uint8_t* d_rgb8, void* stream);
 
+/* saveToFile in one device pass (main.cpp:1837-1857 + stb_image_write.h's stbi_write_bmp layout):
+ * truncating 8-bit conversion and the complete 24-bit BMP file image (54-byte header, BGR,
+ * bottom-up rows padded to 4 bytes) into d_file, which holds rt_bmp24_bytes(width, height) bytes.
+ * The caller copies those bytes to the host (a quarter of the f32 frame) and writes them out. */
+size_t rt_bmp24_bytes(int width, int height);
+int rt_encode_bmp24(rt_ctx* ctx, const float* d_rgb, int width, int height, uint8_t* d_file, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,6 +113,7 @@ _EXPORTS = [
     "rt_scene_set_materials", "rt_scene_set_textures", "rt_scene_set_lights", "rt_scene_set_ambient",
     "rt_scene_set_desc", "rt_scene_commit", "rt_scene_destroy",
     "rt_render", "rt_render_device", "rt_owned_tiles", "rt_unpack_tiles", "rt_quantize_rgb8",
+    "rt_bmp24_bytes", "rt_encode_bmp24",
 ]
 
 _lib = None
@@ -156,6 +157,9 @@ def load_library(path=None):
     lib.rt_owned_tiles.argtypes = [C.POINTER(rt_params), C.c_int, C.c_int, C.POINTER(C.c_uint32)]
     lib.rt_unpack_tiles.argtypes = [vp, vp, C.POINTER(rt_params), C.c_int, C.c_int, vp, vp]
     lib.rt_quantize_rgb8.argtypes = [vp, vp, C.c_size_t, vp, vp]
+    lib.rt_bmp24_bytes.argtypes = [C.c_int, C.c_int]
+    lib.rt_bmp24_bytes.restype = C.c_size_t
+    lib.rt_encode_bmp24.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
     if path == LIB_PATH:
         _lib = lib
     return lib

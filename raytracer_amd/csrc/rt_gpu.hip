@@ -368,6 +368,22 @@ __global__ void __launch_bounds__(RT_BLOCK) k_quantize(const float* rgb, uint8_t
         out[i] = (uint8_t)(int)(rgb[i] * 255.0f);
 }
 
+struct BmpHeader { uint8_t b[54]; };
+// one thread per output byte of a row quad would be finer-grained than needed: one thread per pixel
+__global__ void __launch_bounds__(RT_BLOCK) k_bmp24(const float* rgb, uint8_t* file, int width, int height, uint32_t row_bytes, BmpHeader hdr)
+{
+    const size_t npx = (size_t)width * (size_t)height;
+    for (size_t i = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; i < npx; i += (size_t)gridDim.x * RT_BLOCK) {
+        const uint32_t y = (uint32_t)(i / (size_t)width), x = (uint32_t)(i % (size_t)width);
+        uint8_t* o = file + 54 + (size_t)((uint32_t)height - 1u - y) * row_bytes + (size_t)x * 3;
+        o[2] = (uint8_t)(int)(rgb[i * 3 + 0] * 255.0f);
+        o[1] = (uint8_t)(int)(rgb[i * 3 + 1] * 255.0f);
+        o[0] = (uint8_t)(int)(rgb[i * 3 + 2] * 255.0f);
+        if (x == (uint32_t)width - 1u) for (uint32_t k = (uint32_t)width * 3u; k < row_bytes; ++k) o[3 + (k - (uint32_t)width * 3u)] = 0;
+        if (i < 54) file[i] = hdr.b[i];
+    }
+}
+
 // ---- context / scene objects ------------------------------------------------------------------------
 struct rt_ctx {
     int device = 0;
@@ -923,6 +939,35 @@ int rt_quantize_rgb8(rt_ctx* ctx, const float* d_rgb, size_t num_pixels, uint8_t
     HIPCHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     if (num_pixels) hipLaunchKernelGGL(k_quantize, dim3(grid_for(num_pixels * 3)), dim3(RT_BLOCK), 0, st, d_rgb, d_rgb8, num_pixels * 3);
+    HIPCHECK(ctx, hipGetLastError());
+    if (!stream) HIPCHECK(ctx, hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+size_t rt_bmp24_bytes(int width, int height)
+{
+    if (width <= 0 || height <= 0) return 0;
+    const size_t row = ((size_t)width * 3 + 3) & ~(size_t)3;
+    return 54 + row * (size_t)height;
+}
+
+int rt_encode_bmp24(rt_ctx* ctx, const float* d_rgb, int width, int height, uint8_t* d_file, void* stream)
+{
+    if (!ctx) return RT_ERR_INVALID;
+    if (!d_rgb || !d_file || width <= 0 || height <= 0) { ctx->error = "rt_encode_bmp24: null buffer or empty image"; return RT_ERR_INVALID; }
+    const size_t total = rt_bmp24_bytes(width, height);
+    if (total > 0xFFFFFFFFull) { ctx->error = "rt_encode_bmp24: image too large for a BMP"; return RT_ERR_UNSUPPORTED; }
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIPCHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t row = (uint32_t)(((size_t)width * 3 + 3) & ~(size_t)3);
+    BmpHeader h{};
+    auto put32 = [&](int at, uint32_t v) { for (int k = 0; k < 4; ++k) h.b[at + k] = (uint8_t)(v >> (8 * k)); };
+    h.b[0] = 'B'; h.b[1] = 'M';
+    put32(2, (uint32_t)total); put32(10, 54);
+    put32(14, 40); put32(18, (uint32_t)width); put32(22, (uint32_t)height);
+    h.b[26] = 1; h.b[28] = 24;
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    hipLaunchKernelGGL(k_bmp24, dim3(grid_for((size_t)width * height)), dim3(RT_BLOCK), 0, st, d_rgb, d_file, width, height, row, h);
     HIPCHECK(ctx, hipGetLastError());
     if (!stream) HIPCHECK(ctx, hipStreamSynchronize(st));
     return RT_OK;

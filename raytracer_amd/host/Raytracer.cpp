@@ -2,6 +2,9 @@
 // the arrays of include/rt_amd.h, the render calls, the thread pool, the BMP writer and the small
 // OBJ / PPM / TGA readers.  Links against librt_amd.so only.
 #include "Raytracer.hpp"
+#include <climits>
+#include <algorithm>
+#include <cstring>
 
 #include <algorithm>
 
@@ -121,7 +124,7 @@ void ensure_uploaded(Gpu& g, const World& w)
     g.world = &w; g.revision = w.mRevision;
 }
 
-void render_rect(int y0, int y1, int x0, int x1, Camera const& camera, std::shared_ptr<World> const& world, rt_stats* stats)
+void render_rect(int y0, int y1, int x0, int x1, rt_camera cam, std::shared_ptr<World> const& world, rt_stats* stats)
 {
     Gpu& g = gpu();
     std::lock_guard<std::mutex> lk(g.mu);   // pool threads calling raytrace() concurrently serialise here
@@ -135,7 +138,6 @@ void render_rect(int y0, int y1, int x0, int x1, Camera const& camera, std::shar
     p.max_depth = world->maxDepth; p.light_attenuation = (float)lightAttenuationFactor; p.seed = world->seed;
     if (stats) p.flags = RT_FLAG_TIMING;
     static_assert(sizeof(Colour) == 3 * sizeof(float), "Colour must be three packed floats");
-    rt_camera cam = camera.toC();
     if (rt_render(g.scene, &cam, &p, reinterpret_cast<float*>(world->image.data()), nullptr, nullptr, stats) != RT_OK) fail("rt_render", g.ctx);
 }
 
@@ -143,12 +145,16 @@ void render_rect(int y0, int y1, int x0, int x1, Camera const& camera, std::shar
 
 void raytrace(int beginBlockY, int endBlockY, int beginBlockX, int endBlockX, Camera const& camera, std::shared_ptr<World> const& world)
 {
-    render_rect(beginBlockY, endBlockY, beginBlockX, endBlockX, camera, world, nullptr);
+    if (ThreadPool* pool = ThreadPool::current()) {   // inside a pool job: coalesced at waitDone()
+        pool->defer(ThreadPool::DeferredTile{beginBlockY, endBlockY, beginBlockX, endBlockX, camera.toC(), world});
+        return;
+    }
+    render_rect(beginBlockY, endBlockY, beginBlockX, endBlockX, camera.toC(), world, nullptr);
 }
 
 void render(Camera const& camera, std::shared_ptr<World> const& world, rt_stats* stats)
 {
-    render_rect(0, (int)world->height, 0, (int)world->width, camera, world, stats);
+    render_rect(0, (int)world->height, 0, (int)world->width, camera.toC(), world, stats);
 }
 
 // ---- meshes ----------------------------------------------------------------------------------------
@@ -184,8 +190,57 @@ ThreadPool::ThreadPool(unsigned int const& numThreads)
 {
     for (unsigned i = 0; i < std::max(1u, numThreads); ++i) mThreads.emplace_back(&ThreadPool::loopFunction, this);
 }
+namespace { thread_local ThreadPool* tl_pool = nullptr; }
+ThreadPool* ThreadPool::current() { return tl_pool; }
+void ThreadPool::defer(DeferredTile t)
+{
+    std::lock_guard<std::mutex> lk(mDeferredMutex);
+    mDeferred.push_back(std::move(t));
+}
+
+// Renders what the finished jobs recorded.  Tiles of one (world, camera) whose rectangles are pairwise
+// disjoint and exactly cover their bounding rectangle become one launch; anything else is rendered
+// rectangle by rectangle, in submission order.
+void ThreadPool::flushDeferred()
+{
+    std::vector<DeferredTile> all;
+    {
+        std::lock_guard<std::mutex> lk(mDeferredMutex);
+        all.swap(mDeferred);
+    }
+    std::vector<char> done(all.size(), 0);
+    for (size_t i = 0; i < all.size(); ++i) {
+        if (done[i]) continue;
+        std::vector<size_t> grp;
+        for (size_t j = i; j < all.size(); ++j)
+            if (!done[j] && all[j].world == all[i].world && std::memcmp(&all[j].camera, &all[i].camera, sizeof(rt_camera)) == 0) { grp.push_back(j); done[j] = 1; }
+        int y0 = INT_MAX, y1 = INT_MIN, x0 = INT_MAX, x1 = INT_MIN;
+        long long area = 0;
+        bool ok = true;
+        for (size_t j : grp) {
+            const DeferredTile& t = all[j];
+            if (t.y1 <= t.y0 || t.x1 <= t.x0) { ok = false; break; }
+            y0 = std::min(y0, t.y0); y1 = std::max(y1, t.y1); x0 = std::min(x0, t.x0); x1 = std::max(x1, t.x1);
+            area += (long long)(t.y1 - t.y0) * (t.x1 - t.x0);
+        }
+        ok = ok && area == (long long)(y1 - y0) * (x1 - x0);
+        if (ok) {   // equal area + pairwise disjoint = exact tiling (sweep over the tiles sorted by row)
+            std::vector<size_t> byrow(grp);
+            std::sort(byrow.begin(), byrow.end(), [&](size_t a, size_t b) { return all[a].y0 < all[b].y0; });
+            for (size_t a = 0; a < byrow.size() && ok; ++a)
+                for (size_t b = a + 1; b < byrow.size() && all[byrow[b]].y0 < all[byrow[a]].y1; ++b) {
+                    const DeferredTile &p = all[byrow[a]], &q = all[byrow[b]];
+                    if (p.x0 < q.x1 && q.x0 < p.x1) { ok = false; break; }
+                }
+        }
+        if (ok) { render_rect(y0, y1, x0, x1, all[i].camera, all[i].world, nullptr); ++mLaunches; }
+        else for (size_t j : grp) { render_rect(all[j].y0, all[j].y1, all[j].x0, all[j].x1, all[j].camera, all[j].world, nullptr); ++mLaunches; }
+    }
+}
+
 void ThreadPool::loopFunction()
 {
+    tl_pool = this;
     for (;;) {
         std::function<void()> job;
         {
@@ -213,11 +268,15 @@ void ThreadPool::startJob(std::function<void()> job)
 }
 void ThreadPool::waitDone()
 {
-    std::unique_lock<std::mutex> lock(mQueueMutex);
-    mComplCondition.wait(lock, [&] { return mPending == 0; });
+    {
+        std::unique_lock<std::mutex> lock(mQueueMutex);
+        mComplCondition.wait(lock, [&] { return mPending == 0; });
+    }
+    flushDeferred();
 }
 ThreadPool::~ThreadPool()
 {
+    waitDone();   // nothing recorded is lost when the caller never waited
     {
         std::unique_lock<std::mutex> lock(mQueueMutex);
         mTerminatePool = true;

@@ -116,14 +116,28 @@ public:
     std::vector<unsigned char> mImage;
 };
 
-class ThreadPool {   // Raytracer.hpp:119-143; same interface, predicate-based completion
+class World;
+// Raytracer.hpp:119-143; same interface, predicate-based completion.  raytrace() calls made
+// from inside a pool job are not rendered one by one: the job records its rectangle and waitDone()
+// renders everything recorded in as few GPU launches as possible (one, when the rectangles tile a
+// rectangle, as the 1600 tile jobs of the reference's main() do).  world->image is complete when
+// waitDone() returns, which is where the reference's main() reads it.
+class ThreadPool {
 public:
     explicit ThreadPool(unsigned int const& numThreads);
     void startJob(std::function<void()> job);
     void waitDone();
     ~ThreadPool();
+    struct DeferredTile { int y0, y1, x0, x1; rt_camera camera; std::shared_ptr<World> world; };
+    void defer(DeferredTile t);          // used by raytrace()
+    static ThreadPool* current();        // the pool whose job the calling thread is running, or nullptr
+    unsigned launches() const { return mLaunches; }   // GPU launches made by waitDone() so far
 private:
     void loopFunction();
+    void flushDeferred();
+    std::mutex mDeferredMutex;
+    std::vector<DeferredTile> mDeferred;
+    unsigned mLaunches{0};
     bool mTerminatePool{false};
     int mPending{0};
     std::vector<std::thread> mThreads;

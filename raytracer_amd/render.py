@@ -94,6 +94,13 @@ class Renderer:
     def quantize_rgb8(self, d_rgb, num_pixels, d_rgb8, stream=None):
         self._check(self.lib.rt_quantize_rgb8(self.ctx, d_rgb, num_pixels, d_rgb8, stream), "rt_quantize_rgb8")
 
+    def bmp24_bytes(self, width, height):
+        return int(self.lib.rt_bmp24_bytes(int(width), int(height)))
+
+    def encode_bmp24(self, d_rgb, width, height, d_file, stream=None):
+        """saveToFile on the device: f32 RGB frame -> complete 24-bit BMP file image (device pointers)."""
+        self._check(self.lib.rt_encode_bmp24(self.ctx, d_rgb, int(width), int(height), d_file, stream), "rt_encode_bmp24")
+
     def close(self):
         if self.scene is not None:
             self.lib.rt_scene_destroy(self.scene)

@@ -190,3 +190,19 @@ def test_device_outputs_slabs_unpack_and_quantize(gpu):
     gpu.quantize_rgb8(frame.data_ptr(), 136 * 200, rgb8.data_ptr())
     torch.cuda.synchronize()
     assert np.array_equal(rgb8.cpu().numpy(), util.quantize(full))
+    # the whole saveToFile on the device: byte-identical to the host writer (stbi_write_bmp layout);
+    # 202 px wide rows need 2 bytes of padding
+    from raytracer_amd.render import save_bmp
+    import os, tempfile
+    for w in (200, 101):
+        h = 136 * 200 // w // 2
+        sub = frame.reshape(-1, 3)[: w * h].reshape(h, w, 3).contiguous()
+        nbytes = gpu.bmp24_bytes(w, h)
+        assert nbytes == 54 + ((w * 3 + 3) // 4 * 4) * h
+        buf = torch.full((nbytes,), 0xAA, dtype=torch.uint8, device=dev)
+        gpu.encode_bmp24(sub.data_ptr(), w, h, buf.data_ptr())
+        torch.cuda.synchronize()
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "x.bmp")
+            save_bmp(path, sub.cpu().numpy())
+            assert buf.cpu().numpy().tobytes() == open(path, "rb").read()

@@ -57,6 +57,7 @@ def test_cpp_scene_script_matches_python_host(gpu, tmp_path):
     r = subprocess.run([EXE, str(tmp_path), out, "200", "200"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert "Running time is" in r.stdout
+    assert "tile jobs: 1600, GPU launches: 1" in r.stdout, r.stdout   # the 40x40 jobs coalesce at waitDone()
     got = read_bmp(out)
     out2 = str(tmp_path / "whole.bmp")
     r = subprocess.run([EXE, str(tmp_path), out2, "200", "200", "whole"], capture_output=True, text=True, timeout=120)
