@@ -3,6 +3,7 @@
 // OBJ / PPM / TGA readers.  Links against librt_amd.so only.
 #include "Raytracer.hpp"
 #include <climits>
+#include <cstdlib>
 #include <algorithm>
 #include <cstring>
 
@@ -305,11 +306,188 @@ void saveToFile(std::string const& filename, std::size_t width, std::size_t heig
 }
 
 // ---- small readers -------------------------------------------------------------------------------------
+// ---- PNG -> RGBA8 (what stbi_load(path, .., STBI_rgb_alpha) hands the reference, main.cpp:147-165) --------
+// DEFLATE (RFC 1951) with canonical-Huffman decoding by code length counts, zlib framing (RFC 1950), PNG
+// chunks / filters (ISO 15948).  Non-interlaced images of every colour type; 16-bit samples keep their
+// high byte, sub-byte grey samples are scaled to 0..255, palettes use tRNS for alpha.
+namespace {
+struct BitReader {
+    const unsigned char* p; size_t n, pos = 0; uint32_t buf = 0; int cnt = 0; bool err = false;
+    uint32_t bits(int k)
+    {
+        while (cnt < k) { if (pos >= n) { err = true; return 0; } buf |= (uint32_t)p[pos++] << cnt; cnt += 8; }
+        uint32_t v = k ? (buf & ((1u << k) - 1u)) : 0u;
+        buf >>= k; cnt -= k;
+        return v;
+    }
+};
+struct Huffman {
+    uint16_t count[16] = {0}, symbol[288] = {0};
+    void build(const unsigned char* len, int n)
+    {
+        std::fill(count, count + 16, (uint16_t)0);
+        for (int i = 0; i < n; ++i) count[len[i]]++;
+        uint16_t offs[16]; offs[1] = 0;
+        for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
+        for (int i = 0; i < n; ++i) if (len[i]) symbol[offs[len[i]]++] = (uint16_t)i;
+        count[0] = 0;
+    }
+    int decode(BitReader& br) const
+    {
+        int code = 0, first = 0, index = 0;
+        for (int l = 1; l <= 15; ++l) {
+            code |= (int)br.bits(1);
+            if (br.err) return -1;
+            int c = count[l];
+            if (code - c < first) return symbol[index + (code - first)];
+            index += c; first += c; first <<= 1; code <<= 1;
+        }
+        return -1;
+    }
+};
+bool inflate_zlib(const std::vector<unsigned char>& z, std::vector<unsigned char>& out)
+{
+    if (z.size() < 6 || (z[0] & 15) != 8 || ((z[0] << 8) | z[1]) % 31 != 0 || (z[1] & 32)) return false;
+    BitReader br{z.data() + 2, z.size() - 2};
+    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint16_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint16_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    for (int last = 0; !last;) {
+        last = (int)br.bits(1);
+        const int type = (int)br.bits(2);
+        if (br.err) return false;
+        if (type == 0) {
+            br.buf = 0; br.cnt = 0;
+            if (br.pos + 4 > br.n) return false;
+            const unsigned len = br.p[br.pos] | (br.p[br.pos + 1] << 8), nlen = br.p[br.pos + 2] | (br.p[br.pos + 3] << 8);
+            br.pos += 4;
+            if ((len ^ 0xFFFFu) != nlen || br.pos + len > br.n) return false;
+            out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
+            br.pos += len;
+            continue;
+        }
+        if (type == 3) return false;
+        Huffman lit, dist;
+        unsigned char lens[320];
+        if (type == 1) {
+            for (int i = 0; i < 288; ++i) lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+            lit.build(lens, 288);
+            for (int i = 0; i < 30; ++i) lens[i] = 5;
+            dist.build(lens, 30);
+        } else {
+            const int nlen = (int)br.bits(5) + 257, ndist = (int)br.bits(5) + 1, ncode = (int)br.bits(4) + 4;
+            static const unsigned char order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            if (br.err || nlen > 286 || ndist > 30) return false;
+            unsigned char cl[19] = {0};
+            for (int i = 0; i < ncode; ++i) cl[order[i]] = (unsigned char)br.bits(3);
+            Huffman lencode; lencode.build(cl, 19);
+            for (int i = 0; i < nlen + ndist;) {
+                int sym = lencode.decode(br);
+                if (sym < 0) return false;
+                if (sym < 16) { lens[i++] = (unsigned char)sym; continue; }
+                int rep, val = 0;
+                if (sym == 16) { if (i == 0) return false; val = lens[i - 1]; rep = 3 + (int)br.bits(2); }
+                else if (sym == 17) rep = 3 + (int)br.bits(3);
+                else rep = 11 + (int)br.bits(7);
+                if (i + rep > nlen + ndist) return false;
+                while (rep--) lens[i++] = (unsigned char)val;
+            }
+            if (lens[256] == 0) return false;
+            lit.build(lens, nlen);
+            dist.build(lens + nlen, ndist);
+        }
+        for (;;) {
+            int sym = lit.decode(br);
+            if (sym < 0 || br.err) return false;
+            if (sym < 256) { out.push_back((unsigned char)sym); continue; }
+            if (sym == 256) break;
+            sym -= 257;
+            if (sym >= 29) return false;
+            const int len = lbase[sym] + (int)br.bits(lext[sym]);
+            const int ds = dist.decode(br);
+            if (ds < 0 || ds >= 30) return false;
+            const size_t d = dbase[ds] + br.bits(dext[ds]);
+            if (br.err || d > out.size()) return false;
+            for (int k = 0; k < len; ++k) out.push_back(out[out.size() - d]);
+        }
+    }
+    return true;
+}
+
+bool decode_png(const std::vector<unsigned char>& f, int& W, int& H, std::vector<unsigned char>& rgba)
+{
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (f.size() < 8 || std::memcmp(f.data(), sig, 8) != 0) return false;
+    auto be32 = [&](size_t o) { return ((uint32_t)f[o] << 24) | ((uint32_t)f[o + 1] << 16) | ((uint32_t)f[o + 2] << 8) | f[o + 3]; };
+    uint32_t w = 0, h = 0; int depth = 0, ctype = 0, interlace = 0;
+    std::vector<unsigned char> idat, plte, trns;
+    for (size_t o = 8; o + 12 <= f.size();) {
+        const uint32_t len = be32(o);
+        const std::string tag(f.begin() + o + 4, f.begin() + o + 8);
+        if (o + 12 + (size_t)len > f.size()) return false;
+        const unsigned char* d = f.data() + o + 8;
+        if (tag == "IHDR" && len >= 13) { w = be32(o + 8); h = be32(o + 12); depth = d[8]; ctype = d[9]; interlace = d[12]; }
+        else if (tag == "PLTE") plte.assign(d, d + len);
+        else if (tag == "tRNS") trns.assign(d, d + len);
+        else if (tag == "IDAT") idat.insert(idat.end(), d, d + len);
+        else if (tag == "IEND") break;
+        o += 12 + (size_t)len;
+    }
+    const int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!w || !h || w > 32768 || h > 32768 || !channels || interlace != 0) return false;
+    if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) return false;
+    if (ctype == 3 && (depth == 16 || plte.size() < 3)) return false;
+    std::vector<unsigned char> raw;
+    if (!inflate_zlib(idat, raw)) return false;
+    const size_t bpp = std::max<size_t>(1, (size_t)channels * depth / 8), stride = ((size_t)w * channels * depth + 7) / 8;
+    if (raw.size() < (stride + 1) * h) return false;
+    std::vector<unsigned char> prev(stride, 0), cur(stride);
+    rgba.assign((size_t)w * h * 4, 255);
+    for (uint32_t y = 0; y < h; ++y) {
+        const unsigned char* src = &raw[(stride + 1) * y];
+        const int ft = src[0];
+        if (ft > 4) return false;
+        for (size_t i = 0; i < stride; ++i) {
+            const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+            int pred = 0;
+            if (ft == 1) pred = a;
+            else if (ft == 2) pred = b;
+            else if (ft == 3) pred = (a + b) >> 1;
+            else if (ft == 4) { const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+            cur[i] = (unsigned char)(src[1 + i] + pred);
+        }
+        for (uint32_t x = 0; x < w; ++x) {
+            unsigned char* o = &rgba[((size_t)y * w + x) * 4];
+            auto sample = [&](int ch) -> unsigned {   // 8-bit view of sample ch of pixel x (raw index for palettes)
+                if (depth == 8) return cur[(size_t)x * channels + ch];
+                if (depth == 16) return cur[((size_t)x * channels + ch) * 2];
+                const unsigned bit = x * (unsigned)depth, v = (cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1u);
+                return ctype == 3 ? v : v * (255u / ((1u << depth) - 1u));
+            };
+            if (ctype == 0) { o[0] = o[1] = o[2] = (unsigned char)sample(0); }
+            else if (ctype == 2) { o[0] = (unsigned char)sample(0); o[1] = (unsigned char)sample(1); o[2] = (unsigned char)sample(2); }
+            else if (ctype == 3) { const unsigned i = sample(0); if (i * 3 + 2 < plte.size()) { o[0] = plte[i * 3]; o[1] = plte[i * 3 + 1]; o[2] = plte[i * 3 + 2]; } else { o[0] = o[1] = o[2] = 0; } o[3] = i < trns.size() ? trns[i] : 255; }
+            else if (ctype == 4) { o[0] = o[1] = o[2] = (unsigned char)sample(0); o[3] = (unsigned char)sample(1); }
+            else { o[0] = (unsigned char)sample(0); o[1] = (unsigned char)sample(1); o[2] = (unsigned char)sample(2); o[3] = (unsigned char)sample(3); }
+        }
+        prev.swap(cur);
+    }
+    W = (int)w; H = (int)h;
+    return true;
+}
+} // namespace
+
 ImageTexture::ImageTexture(std::string const& path)
 {
     std::ifstream f(path, std::ios::binary);
     if (!f) return;
     std::vector<unsigned char> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (d.size() > 8 && d[0] == 0x89 && d[1] == 'P' && d[2] == 'N' && d[3] == 'G') {
+        int w = 0, h = 0;
+        if (decode_png(d, w, h, mImage)) { mWidth = w; mHeight = h; mSet = true; } else mImage.clear();
+        return;
+    }
     if (d.size() > 2 && d[0] == 'P' && d[1] == '6') {
         std::istringstream hs(std::string(d.begin(), d.begin() + std::min<size_t>(d.size(), 64)));
         std::string magic; int w = 0, h = 0, mx = 0;

@@ -69,3 +69,104 @@ def test_cpp_scene_script_matches_python_host(gpu, tmp_path):
     want = util.quantize(rgb)
     bad = np.argwhere((got != want).any(axis=2))
     assert len(bad) == 0, f"{len(bad)} pixels differ, first {bad[:8].tolist()}, got {got[tuple(bad[0])]} want {want[tuple(bad[0])]}"
+
+
+# ---- PNG decoder of the C++ host: no GPU needed ------------------------------------------
+DUMP = os.path.join(conftest.ROOT, "examples", "texture_dump")
+
+
+def _png(w, h, ctype, depth, rows, plte=None, trns=None, filt=None, level=6, split=1):
+    """Minimal PNG writer: rows = h byte strings of packed samples; filt(y) -> filter type per row."""
+    import struct
+    import zlib
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    bpp = max(1, channels * depth // 8)
+    raw = b""
+    prev = bytes(len(rows[0]))
+    for y, row in enumerate(rows):
+        ft = filt(y) if filt else 0
+        out = bytearray(len(row))
+        for i, v in enumerate(row):
+            a = row[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            if ft == 0: pred = 0
+            elif ft == 1: pred = a
+            elif ft == 2: pred = b
+            elif ft == 3: pred = (a + b) >> 1
+            else:
+                pp = a + b - c
+                pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - c)
+                pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            out[i] = (v - pred) & 255
+        raw += bytes([ft]) + bytes(out)
+        prev = row
+    z = zlib.compress(raw, level)
+    parts = [z[i * len(z) // split:(i + 1) * len(z) // split] for i in range(split)]
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+    if plte is not None: png += chunk(b"PLTE", plte)
+    if trns is not None: png += chunk(b"tRNS", trns)
+    for part in parts: png += chunk(b"IDAT", part)
+    return png + chunk(b"IEND", b"")
+
+
+def _dump(path, tmp_path):
+    out = str(tmp_path / "dump.rgba")
+    r = subprocess.run([DUMP, path, out], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    b = open(out, "rb").read()
+    nl = b.index(b"\n")
+    w, h = (int(x) for x in b[:nl].split())
+    return np.frombuffer(b[nl + 1:], np.uint8).reshape(h, w, 4)
+
+
+def test_png_decoder_matches_stb_conventions(tmp_path):
+    """Every colour type / bit depth / filter, stored + fixed + dynamic deflate blocks, split IDATs;
+    expected RGBA8 follows stbi_load(.., STBI_rgb_alpha): grey -> (g,g,g,255), 16 bit -> high byte,
+    sub-byte grey scaled to 0..255, palette + tRNS."""
+    if not os.path.exists(DUMP):
+        subprocess.run(["make", "-C", os.path.dirname(DUMP)], check=True, stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(7)
+    w, h = 37, 23
+    cases = []
+    # smooth + noisy content so that dynamic Huffman blocks with long matches and literals both occur
+    base = (np.add.outer(np.arange(h) * 5, np.arange(w) * 3)[:, :, None] + np.arange(4)[None, None, :] * 40) % 256
+    noisy = rng.integers(0, 256, (h, w, 4))
+    for name, img in (("smooth", base), ("noisy", noisy)):
+        img = img.astype(np.uint8)
+        for level in (0, 1, 9):
+            filt = (lambda y: y % 5)
+            rgba = img
+            cases.append((f"rgba8_{name}_{level}", _png(w, h, 6, 8, [bytes(r.tobytes()) for r in rgba], filt=filt, level=level, split=3), rgba))
+            rgb = img[:, :, :3]
+            exp = np.concatenate([rgb, np.full((h, w, 1), 255, np.uint8)], 2)
+            cases.append((f"rgb8_{name}_{level}", _png(w, h, 2, 8, [bytes(r.tobytes()) for r in rgb], filt=filt, level=level), exp))
+    g = base[:, :, 0].astype(np.uint8)
+    cases.append(("grey8", _png(w, h, 0, 8, [bytes(r.tobytes()) for r in g], filt=lambda y: 4), np.stack([g, g, g, np.full_like(g, 255)], 2)))
+    ga = base[:, :, :2].astype(np.uint8)
+    cases.append(("greyalpha8", _png(w, h, 4, 8, [bytes(r.tobytes()) for r in ga], filt=lambda y: 3), np.stack([ga[:, :, 0]] * 3 + [ga[:, :, 1]], 2)))
+    hi = noisy[:, :, :3].astype(np.uint8); lo = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    rows16 = [bytes(np.stack([hi[y], lo[y]], 2).tobytes()) for y in range(h)]
+    cases.append(("rgb16", _png(w, h, 2, 16, rows16, filt=lambda y: 1), np.concatenate([hi, np.full((h, w, 1), 255, np.uint8)], 2)))
+    idx = rng.integers(0, 16, (h, w)).astype(np.uint8)
+    plte = rng.integers(0, 256, (16, 3)).astype(np.uint8); trns = rng.integers(0, 256, 9).astype(np.uint8)
+    exp = np.concatenate([plte[idx], np.where(idx < 9, np.concatenate([trns, np.full(7, 255, np.uint8)])[idx], 255)[:, :, None].astype(np.uint8)], 2)
+    cases.append(("pal8", _png(w, h, 3, 8, [bytes(r.tobytes()) for r in idx], plte=plte.tobytes(), trns=trns.tobytes()), exp))
+    packed4 = [bytes(np.packbits(np.unpackbits(r[:, None], axis=1)[:, 4:].reshape(-1)).tobytes()) for r in idx]
+    cases.append(("pal4", _png(w, h, 3, 4, packed4, plte=plte.tobytes(), trns=trns.tobytes()), exp))
+    g2 = rng.integers(0, 4, (h, w)).astype(np.uint8)
+    packed2 = [bytes(np.packbits(np.unpackbits(r[:, None], axis=1)[:, 6:].reshape(-1)).tobytes()) for r in g2]
+    cases.append(("grey2", _png(w, h, 0, 2, packed2), np.stack([g2 * 85] * 3 + [np.full_like(g2, 255)], 2)))
+    for name, data, want in cases:
+        path = str(tmp_path / (name + ".png"))
+        open(path, "wb").write(data)
+        got = _dump(path, tmp_path)
+        assert got.shape == want.shape and np.array_equal(got, want), name
+    ref_png = "/root/reference/Raytracer/models/teapot/default.png"
+    if os.path.exists(ref_png):   # the reference's own texture decodes to the checker the scenes generate
+        tex = scenes.checker_texture()
+        assert np.array_equal(_dump(ref_png, tmp_path), tex.rgba)
