@@ -811,6 +811,7 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
         ctx->batch_bytes = need;
     }
     carve_batch(B, (char*)ctx->batch_mem, P, levels_alloc, nl, n2);
+    if (S.debug & 8u) B.bq_cap = std::min<uint32_t>(B.bq_cap, 3000u);   // test switch: a BVH queue that overflows (inline traversal path)
     B.counters = ctx->d_counters;
     B.stats = ctx->d_stats;
 

@@ -206,3 +206,23 @@ def test_device_outputs_slabs_unpack_and_quantize(gpu):
             path = os.path.join(td, "x.bmp")
             save_bmp(path, sub.cpu().numpy())
             assert buf.cpu().numpy().tobytes() == open(path, "rb").read()
+
+
+@pytest.mark.gpu
+def test_bvh_queue_overflow_falls_back_inline(gpu):
+    """RT_DEBUG=8 (read at rt_scene_commit) caps the compacted BVH queue at 3000 items, so most
+    mesh rays take the inline traversal in k_trace / k_ao and the chunked appends run past the
+    capacity: the frame must not change by a bit."""
+    import os
+    name, world, params = CASES[0]
+    p = capi.rt_params.from_buffer_copy(params)
+    gpu.upload(world)
+    want, wid, wt, _ = gpu.render(world.camera, p, ids=True)
+    os.environ["RT_DEBUG"] = "8"
+    try:
+        gpu.upload(world)
+        got, gid, gt, _ = gpu.render(world.camera, p, ids=True)
+    finally:
+        del os.environ["RT_DEBUG"]
+        gpu.upload(world)
+    assert np.array_equal(gid, wid) and util.bits_equal(gt, wt) and util.bits_equal(got, want)
