@@ -1,5 +1,10 @@
 // rt_scene.cpp — validation, reference-structure rebuild and triangle-BVH construction.
 #include "rt_scene.hpp"
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
 
 #include <algorithm>
 #include <cmath>
@@ -145,7 +150,49 @@ int HostScene::reference_hierarchy(const rt_bvh& b, std::vector<RefNode>& H)
     while (layer != 1) {
         const size_t next_layer = (size_t)std::ceil((float)layer / 2.0f);
         const int end = (int)H.size(), begin = (int)(H.size() - layer);
-        for (size_t made = 0; made < next_layer; ++made) {
+        auto join = [&](int bi, int bk) {
+            RefNode n{};
+            n.leaf = false; n.left = (uint32_t)bi; n.right = (uint32_t)bk; n.accessed = false;
+            n.box = H[bi].box; box_merge(n.box, H[bk].box);
+            H.push_back(n);
+            H[bi].accessed = true; H[bk].accessed = true;
+        };
+        auto copy_up = [&] {
+            for (int i = end - 1; i >= begin; --i)
+                if (!H[i].accessed) { RefNode c = H[i]; H.push_back(c); H[i].accessed = true; break; }
+        };
+        size_t made = 0;
+        if (layer <= 8192 && !force_reference_scan) {
+            // Same result as the reference's scan (below) in O(n^2 log n): distances inside a layer never
+            // change, so "closest remaining pair, highest i then highest k first among equals" is the order
+            // of all pairs sorted by (distance, -i, -k), skipping pairs with a used end.
+            struct Pair { float dist; int i, k; };
+            std::vector<Pair> pairs;
+            pairs.reserve(layer * (layer - 1) / 2);
+            std::vector<float> cen(layer * 3);
+            for (int i = begin; i < end; ++i) centroid(H[i].box, &cen[(size_t)(i - begin) * 3]);
+            for (int i = end - 1; i > begin; --i) {
+                const float* ci = &cen[(size_t)(i - begin) * 3];
+                for (int k = i - 1; k >= begin; --k) {
+                    const float* ck = &cen[(size_t)(k - begin) * 3];
+                    float dx = ck[0] - ci[0], dy = ck[1] - ci[1], dz = ck[2] - ci[2];
+                    float dist = sqrtf(dx * dx + dy * dy + dz * dz);   // glm::distance = length(p1 - p0)
+                    if (dist < std::numeric_limits<float>::max()) pairs.push_back(Pair{dist, i, k});
+                }
+            }
+            std::sort(pairs.begin(), pairs.end(), [](const Pair& a, const Pair& b) {
+                if (a.dist != b.dist) return a.dist < b.dist;
+                if (a.i != b.i) return a.i > b.i;
+                return a.k > b.k;
+            });
+            for (const Pair& p : pairs) {
+                if (made == next_layer) break;
+                if (H[p.i].accessed || H[p.k].accessed) continue;
+                join(p.i, p.k); ++made;
+            }
+            for (; made < next_layer; ++made) copy_up();
+        }
+        for (; made < next_layer; ++made) {   // the reference's own O(n^3) scan, kept for very wide layers
             int bi = -1, bk = -1;
             float best = std::numeric_limits<float>::max();
             for (int i = end - 1; i > begin; --i) {
@@ -159,16 +206,8 @@ int HostScene::reference_hierarchy(const rt_bvh& b, std::vector<RefNode>& H)
                     if (dist < best) { best = dist; bi = i; bk = k; }
                 }
             }
-            if (bi < 0) {
-                for (int i = end - 1; i >= begin; --i)
-                    if (!H[i].accessed) { RefNode c = H[i]; H.push_back(c); H[i].accessed = true; break; }
-            } else {
-                RefNode n{};
-                n.leaf = false; n.left = (uint32_t)bi; n.right = (uint32_t)bk; n.accessed = false;
-                n.box = H[bi].box; box_merge(n.box, H[bk].box);
-                H.push_back(n);
-                H[bi].accessed = true; H[bk].accessed = true;
-            }
+            if (bi < 0) copy_up();
+            else join(bi, bk);
         }
         layer = next_layer;
     }
@@ -201,10 +240,126 @@ inline float half_area(const float* mn, const float* mx)
 }
 } // namespace
 
-uint32_t HostScene::mesh_bvh(uint32_t mesh, uint32_t rank_base)
+// The layout after appending parts (rt_scene.hpp: BvhPart) is that of a sequential depth-first build:
+// [node][left subtree][right subtree], triangle slots in leaf order.
+namespace {
+uint32_t relocate(uint32_t ref, uint32_t node_off, uint32_t slot_off)
 {
-    // triangle records carry their absolute rank, so a Mesh reachable through two gate nodes gets two BVH copies
-    if (mesh_root_[mesh] != 0xFFFFFFFFu && mesh_rank_[mesh] == rank_base) return mesh_root_[mesh];
+    if (ref == REF_NONE) return ref;
+    return (ref & REF_LEAF) ? ref + slot_off : ref + node_off;   // slots sit in the low 28 bits and do not overflow them (checked by validate)
+}
+void append_part(HostScene::BvhPart& dst, const HostScene::BvhPart& src, uint32_t& ref)
+{
+    const uint32_t node_off = (uint32_t)(dst.nodes.size() / 4), slot_off = (uint32_t)dst.order.size();
+    for (size_t i = 0; i + 3 < src.nodes.size(); i += 4) {
+        dst.nodes.push_back(src.nodes[i]); dst.nodes.push_back(src.nodes[i + 1]); dst.nodes.push_back(src.nodes[i + 2]);
+        q4 r = src.nodes[i + 3];
+        r.x = u2f(relocate(f2u(r.x), node_off, slot_off)); r.y = u2f(relocate(f2u(r.y), node_off, slot_off));
+        dst.nodes.push_back(r);
+    }
+    dst.order.insert(dst.order.end(), src.order.begin(), src.order.end());
+    dst.max_depth = std::max(dst.max_depth, src.max_depth);
+    ref = relocate(ref, node_off, slot_off);
+}
+
+// returns the (local) child reference for T[lo,hi); `par` = levels of the tree that may still fork threads
+uint32_t build_subtree(std::vector<BuildTri>& T, uint32_t lo, uint32_t hi, int depth, int par, HostScene::BvhPart& out)
+{
+    auto bounds = [&](uint32_t a0, uint32_t a1, float* mn, float* mx) {
+        for (int a = 0; a < 3; ++a) { mn[a] = INFINITY; mx[a] = -INFINITY; }
+        for (uint32_t i = a0; i < a1; ++i)
+            for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], T[i].mn[a]); mx[a] = std::max(mx[a], T[i].mx[a]); }
+    };
+    const uint32_t n = hi - lo;
+    if (n <= kLeafMax) {
+        const uint32_t first = (uint32_t)out.order.size();
+        for (uint32_t i = lo; i < hi; ++i) out.order.push_back(T[i].gid);
+        return REF_LEAF | ((n - 1u) << 28) | first;
+    }
+    out.max_depth = std::max<uint32_t>(out.max_depth, (uint32_t)depth + 1);
+    // centroid bounds
+    float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = lo; i < hi; ++i)
+        for (int a = 0; a < 3; ++a) { cmn[a] = std::min(cmn[a], T[i].c[a]); cmx[a] = std::max(cmx[a], T[i].c[a]); }
+    int best_axis = -1, best_bin = -1;
+    float best_cost = INFINITY;
+    for (int a = 0; a < 3; ++a) {
+        float ext = cmx[a] - cmn[a];
+        if (!(ext > 0.0f)) continue;
+        uint32_t cnt[kBins] = {0};
+        float bmn[kBins][3], bmx[kBins][3];
+        for (int b = 0; b < kBins; ++b) for (int k = 0; k < 3; ++k) { bmn[b][k] = INFINITY; bmx[b][k] = -INFINITY; }
+        float scale = (float)kBins / ext;
+        for (uint32_t i = lo; i < hi; ++i) {
+            int b = std::min(kBins - 1, std::max(0, (int)((T[i].c[a] - cmn[a]) * scale)));
+            cnt[b]++;
+            for (int k = 0; k < 3; ++k) { bmn[b][k] = std::min(bmn[b][k], T[i].mn[k]); bmx[b][k] = std::max(bmx[b][k], T[i].mx[k]); }
+        }
+        float rarea[kBins]; uint32_t rcnt[kBins];
+        float amn[3] = {INFINITY, INFINITY, INFINITY}, amx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        uint32_t c = 0;
+        for (int b = kBins - 1; b > 0; --b) {
+            c += cnt[b];
+            for (int k = 0; k < 3; ++k) { amn[k] = std::min(amn[k], bmn[b][k]); amx[k] = std::max(amx[k], bmx[b][k]); }
+            rcnt[b] = c; rarea[b] = c ? half_area(amn, amx) : 0.0f;
+        }
+        for (int k = 0; k < 3; ++k) { amn[k] = INFINITY; amx[k] = -INFINITY; }
+        c = 0;
+        for (int b = 0; b < kBins - 1; ++b) {
+            c += cnt[b];
+            for (int k = 0; k < 3; ++k) { amn[k] = std::min(amn[k], bmn[b][k]); amx[k] = std::max(amx[k], bmx[b][k]); }
+            if (c == 0 || rcnt[b + 1] == 0) continue;
+            float cost = half_area(amn, amx) * (float)c + rarea[b + 1] * (float)rcnt[b + 1];
+            if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+        }
+    }
+    uint32_t mid = lo;
+    const uint64_t cap_child = (uint64_t)kLeafMax << std::max(0, kMaxDepth - depth - 1);
+    if (best_axis >= 0) {
+        float ext = cmx[best_axis] - cmn[best_axis];
+        float scale = (float)kBins / ext;
+        auto it = std::partition(T.begin() + lo, T.begin() + hi, [&](const BuildTri& t) {
+            int b = std::min(kBins - 1, std::max(0, (int)((t.c[best_axis] - cmn[best_axis]) * scale)));
+            return b <= best_bin;
+        });
+        mid = (uint32_t)(it - T.begin());
+    }
+    if (mid == lo || mid == hi || (uint64_t)(mid - lo) > cap_child || (uint64_t)(hi - mid) > cap_child) {
+        // median split along the widest centroid axis (also the depth-bounding fallback)
+        int a = 0;
+        if (cmx[1] - cmn[1] > cmx[a] - cmn[a]) a = 1;
+        if (cmx[2] - cmn[2] > cmx[a] - cmn[a]) a = 2;
+        mid = lo + n / 2;
+        std::nth_element(T.begin() + lo, T.begin() + mid, T.begin() + hi,
+                         [&](const BuildTri& x, const BuildTri& y) { return x.c[a] < y.c[a]; });
+    }
+    const size_t me = out.nodes.size() / 4;
+    out.nodes.resize(out.nodes.size() + 4);
+    float lmn[3], lmx[3], rmn[3], rmx[3];
+    bounds(lo, mid, lmn, lmx); bounds(mid, hi, rmn, rmx);
+    uint32_t l, r;
+    if (par > 0 && n >= 32768) {   // the two halves touch disjoint ranges of T: build them side by side
+        HostScene::BvhPart lp, rp;
+        std::thread th([&] { l = build_subtree(T, lo, mid, depth + 1, par - 1, lp); });
+        r = build_subtree(T, mid, hi, depth + 1, par - 1, rp);
+        th.join();
+        append_part(out, lp, l);
+        append_part(out, rp, r);
+    } else {
+        l = build_subtree(T, lo, mid, depth + 1, 0, out);
+        r = build_subtree(T, mid, hi, depth + 1, 0, out);
+    }
+    out.nodes[me * 4 + 0] = {lmn[0], lmn[1], lmn[2], lmx[0]};
+    out.nodes[me * 4 + 1] = {lmx[1], lmx[2], rmn[0], rmn[1]};
+    out.nodes[me * 4 + 2] = {rmn[2], rmx[0], rmx[1], rmx[2]};
+    out.nodes[me * 4 + 3] = {u2f(l), u2f(r), 0.0f, 0.0f};
+    return (uint32_t)me;
+}
+} // namespace
+
+// builds the part of one mesh (no rank, no global indices: reusable for every place the mesh is reached from)
+void HostScene::build_mesh_part(uint32_t mesh, int par, BvhPart& part) const
+{
     const rt_mesh& m = meshes[mesh];
     std::vector<BuildTri> T(m.num_triangles);
     for (uint32_t k = 0; k < m.num_triangles; ++k) {
@@ -217,107 +372,56 @@ uint32_t HostScene::mesh_bvh(uint32_t mesh, uint32_t rank_base)
             b.c[a] = 0.5f * (b.mn[a] + b.mx[a]);
         }
     }
-    auto bounds = [&](uint32_t lo, uint32_t hi, float* mn, float* mx) {
-        for (int a = 0; a < 3; ++a) { mn[a] = INFINITY; mx[a] = -INFINITY; }
-        for (uint32_t i = lo; i < hi; ++i)
-            for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], T[i].mn[a]); mx[a] = std::max(mx[a], T[i].mx[a]); }
-    };
-    auto make_leaf = [&](uint32_t lo, uint32_t hi) -> uint32_t {
-        uint32_t first = 0;
-        for (uint32_t i = lo; i < hi; ++i) {
-            uint32_t s = add_triangle_slot(T[i].gid, rank_base + (T[i].gid - m.first_triangle));
-            if (i == lo) first = s;
-        }
-        return REF_LEAF | ((hi - lo - 1u) << 28) | first;
-    };
-    uint32_t max_depth_seen = 0;
-    // returns the child reference for T[lo,hi); inner nodes are appended to fnodes4
-    std::function<uint32_t(uint32_t, uint32_t, int)> build = [&](uint32_t lo, uint32_t hi, int depth) -> uint32_t {
-        const uint32_t n = hi - lo;
-        if (n <= kLeafMax) return make_leaf(lo, hi);
-        max_depth_seen = std::max<uint32_t>(max_depth_seen, (uint32_t)depth + 1);
-        // centroid bounds
-        float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (uint32_t i = lo; i < hi; ++i)
-            for (int a = 0; a < 3; ++a) { cmn[a] = std::min(cmn[a], T[i].c[a]); cmx[a] = std::max(cmx[a], T[i].c[a]); }
-        int best_axis = -1, best_bin = -1;
-        float best_cost = INFINITY;
-        for (int a = 0; a < 3; ++a) {
-            float ext = cmx[a] - cmn[a];
-            if (!(ext > 0.0f)) continue;
-            uint32_t cnt[kBins] = {0};
-            float bmn[kBins][3], bmx[kBins][3];
-            for (int b = 0; b < kBins; ++b) for (int k = 0; k < 3; ++k) { bmn[b][k] = INFINITY; bmx[b][k] = -INFINITY; }
-            float scale = (float)kBins / ext;
-            for (uint32_t i = lo; i < hi; ++i) {
-                int b = std::min(kBins - 1, std::max(0, (int)((T[i].c[a] - cmn[a]) * scale)));
-                cnt[b]++;
-                for (int k = 0; k < 3; ++k) { bmn[b][k] = std::min(bmn[b][k], T[i].mn[k]); bmx[b][k] = std::max(bmx[b][k], T[i].mx[k]); }
-            }
-            float rarea[kBins]; uint32_t rcnt[kBins];
-            float amn[3] = {INFINITY, INFINITY, INFINITY}, amx[3] = {-INFINITY, -INFINITY, -INFINITY};
-            uint32_t c = 0;
-            for (int b = kBins - 1; b > 0; --b) {
-                c += cnt[b];
-                for (int k = 0; k < 3; ++k) { amn[k] = std::min(amn[k], bmn[b][k]); amx[k] = std::max(amx[k], bmx[b][k]); }
-                rcnt[b] = c; rarea[b] = c ? half_area(amn, amx) : 0.0f;
-            }
-            for (int k = 0; k < 3; ++k) { amn[k] = INFINITY; amx[k] = -INFINITY; }
-            c = 0;
-            for (int b = 0; b < kBins - 1; ++b) {
-                c += cnt[b];
-                for (int k = 0; k < 3; ++k) { amn[k] = std::min(amn[k], bmn[b][k]); amx[k] = std::max(amx[k], bmx[b][k]); }
-                if (c == 0 || rcnt[b + 1] == 0) continue;
-                float cost = half_area(amn, amx) * (float)c + rarea[b + 1] * (float)rcnt[b + 1];
-                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
-            }
-        }
-        uint32_t mid = lo;
-        const uint64_t cap_child = (uint64_t)kLeafMax << std::max(0, kMaxDepth - depth - 1);
-        if (best_axis >= 0) {
-            float ext = cmx[best_axis] - cmn[best_axis];
-            float scale = (float)kBins / ext;
-            auto it = std::partition(T.begin() + lo, T.begin() + hi, [&](const BuildTri& t) {
-                int b = std::min(kBins - 1, std::max(0, (int)((t.c[best_axis] - cmn[best_axis]) * scale)));
-                return b <= best_bin;
-            });
-            mid = (uint32_t)(it - T.begin());
-        }
-        if (mid == lo || mid == hi || (uint64_t)(mid - lo) > cap_child || (uint64_t)(hi - mid) > cap_child) {
-            // median split along the widest centroid axis (also the depth-bounding fallback)
-            int a = 0;
-            if (cmx[1] - cmn[1] > cmx[a] - cmn[a]) a = 1;
-            if (cmx[2] - cmn[2] > cmx[a] - cmn[a]) a = 2;
-            mid = lo + n / 2;
-            std::nth_element(T.begin() + lo, T.begin() + mid, T.begin() + hi,
-                             [&](const BuildTri& x, const BuildTri& y) { return x.c[a] < y.c[a]; });
-        }
-        const size_t me = fnodes4.size() / 4;
-        fnodes4.resize(fnodes4.size() + 4);
-        float lmn[3], lmx[3], rmn[3], rmx[3];
-        bounds(lo, mid, lmn, lmx); bounds(mid, hi, rmn, rmx);
-        uint32_t l = build(lo, mid, depth + 1);
-        uint32_t r = build(mid, hi, depth + 1);
-        fnodes4[me * 4 + 0] = {lmn[0], lmn[1], lmn[2], lmx[0]};
-        fnodes4[me * 4 + 1] = {lmx[1], lmx[2], rmn[0], rmn[1]};
-        fnodes4[me * 4 + 2] = {rmn[2], rmx[0], rmx[1], rmx[2]};
-        fnodes4[me * 4 + 3] = {u2f(l), u2f(r), 0.0f, 0.0f};
-        return (uint32_t)me;
-    };
-    uint32_t root;
-    if (m.num_triangles <= kLeafMax) {
-        float mn[3], mx[3];
-        bounds(0, m.num_triangles, mn, mx);
-        root = (uint32_t)(fnodes4.size() / 4);
-        uint32_t leaf = make_leaf(0, m.num_triangles);
-        fnodes4.push_back({mn[0], mn[1], mn[2], mx[0]});
-        fnodes4.push_back({mx[1], mx[2], INFINITY, INFINITY});
-        fnodes4.push_back({INFINITY, -INFINITY, -INFINITY, -INFINITY});
-        fnodes4.push_back({u2f(leaf), u2f((uint32_t)REF_NONE), 0.0f, 0.0f});
+    if (m.num_triangles <= kLeafMax) {   // a single leaf hangs below a one-child root node
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (auto& b : T) for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], b.mn[a]); mx[a] = std::max(mx[a], b.mx[a]); }
+        for (auto& b : T) part.order.push_back(b.gid);
+        const uint32_t leaf = REF_LEAF | ((m.num_triangles - 1u) << 28) | 0u;
+        part.nodes.push_back({mn[0], mn[1], mn[2], mx[0]});
+        part.nodes.push_back({mx[1], mx[2], INFINITY, INFINITY});
+        part.nodes.push_back({INFINITY, -INFINITY, -INFINITY, -INFINITY});
+        part.nodes.push_back({u2f(leaf), u2f((uint32_t)REF_NONE), 0.0f, 0.0f});
+        part.root = 0;
     } else {
-        root = build(0, m.num_triangles, 0);
+        part.root = build_subtree(T, 0, m.num_triangles, 0, par, part);
     }
-    bvh_max_depth = std::max(bvh_max_depth, max_depth_seen);
+}
+
+// All mesh BVHs, built ahead of the emission pass on up to 16 threads: meshes side by side when there are
+// many (config 5: 2500 instances), the top levels of each tree when there are few (config 3: one mesh).
+void HostScene::prebuild_mesh_parts()
+{
+    mesh_part_.clear();
+    mesh_part_.resize(meshes.size());
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const int par = meshes.size() >= hw ? 0 : (hw >= 16 ? 4 : hw >= 8 ? 3 : hw >= 4 ? 2 : hw >= 2 ? 1 : 0);
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (size_t i; (i = next.fetch_add(1)) < meshes.size();) build_mesh_part((uint32_t)i, par, mesh_part_[i]);
+    };
+    const unsigned nthreads = (unsigned)std::min<size_t>(meshes.size(), par > 0 ? 1 : hw);
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+}
+
+uint32_t HostScene::mesh_bvh(uint32_t mesh, uint32_t rank_base)
+{
+    // triangle records carry their absolute rank, so a Mesh reachable through two gate nodes gets two BVH copies
+    if (mesh_root_[mesh] != 0xFFFFFFFFu && mesh_rank_[mesh] == rank_base) return mesh_root_[mesh];
+    const rt_mesh& m = meshes[mesh];
+    const BvhPart& part = mesh_part_[mesh];
+    const uint32_t node_off = (uint32_t)(fnodes4.size() / 4), slot_off = (uint32_t)(tris4.size() / 3);
+    for (size_t i = 0; i + 3 < part.nodes.size(); i += 4) {
+        fnodes4.push_back(part.nodes[i]); fnodes4.push_back(part.nodes[i + 1]); fnodes4.push_back(part.nodes[i + 2]);
+        q4 r = part.nodes[i + 3];
+        r.x = u2f(relocate(f2u(r.x), node_off, slot_off)); r.y = u2f(relocate(f2u(r.y), node_off, slot_off));
+        fnodes4.push_back(r);
+    }
+    for (uint32_t gid : part.order) add_triangle_slot(gid, rank_base + (gid - m.first_triangle));
+    const uint32_t root = relocate(part.root, node_off, slot_off);
+    bvh_max_depth = std::max(bvh_max_depth, part.max_depth);
     mesh_root_[mesh] = root; mesh_rank_[mesh] = rank_base;
     return root;
 }
@@ -483,6 +587,12 @@ int HostScene::build()
         for (uint32_t k = 0; k < multimeshes[i].num_meshes; ++k) box_merge(mm_box_[i], mesh_box_[multimeshes[i].first_mesh + k]);
     }
     mesh_root_.assign(meshes.size(), 0xFFFFFFFFu);
+    const bool timing = getenv("RT_BUILD_TIMING") != nullptr;   // prints where rt_scene_commit's host time goes
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const auto t_begin = now();
+    prebuild_mesh_parts();
+    const auto t_parts = now();
     mesh_rank_.assign(meshes.size(), 0);
 
     for (auto& p : planes) {
@@ -533,7 +643,11 @@ int HostScene::build()
         }
     }
     if (bvh_max_depth > (uint32_t)kMaxDepth + 1) { error = "triangle BVH deeper than the traversal stack"; return RT_ERR_UNSUPPORTED; }
+    const auto t_emit = now();
     quantize_nodes();
+    mesh_part_.clear(); mesh_part_.shrink_to_fit();
+    if (timing) std::fprintf(stderr, "[rt_scene] triangle BVHs %.3f s, gate emission (reference hierarchy, appends) %.3f s, node quantisation %.3f s\n",
+                             secs(t_begin, t_parts), secs(t_parts, t_emit), secs(t_emit, now()));
 
     has_bounce_materials = false;
     for (auto& m : materials) {

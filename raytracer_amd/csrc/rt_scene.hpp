@@ -47,10 +47,19 @@ struct HostScene {
     std::string error;
 
     int build();   // rt_status
+    // One (sub)tree built into its own buffers, with node indices and triangle slots local to them, so that
+    // independent subtrees and meshes can be built on different threads and appended afterwards.
+    struct BvhPart {
+        std::vector<q4> nodes;          // 4 per node: child boxes + {ref0, ref1}
+        std::vector<uint32_t> order;    // global triangle ids in slot order
+        uint32_t max_depth = 0;
+        uint32_t root = REF_NONE;       // reference of the part's root (local)
+    };
 
     // reference hierarchy of one BVHAccel, exposed for tests (node = {leaf,left,right,box})
     struct RefNode { bool leaf; rt_shape_ref shape; Aabb box; uint32_t left, right; bool accessed; };
     int reference_hierarchy(const rt_bvh& b, std::vector<RefNode>& out);
+    bool force_reference_scan = false;   // tests: use the reference's own O(n^3) pairing scan for every layer
 
 private:
     std::vector<Aabb> mesh_box_, mm_box_;
@@ -59,6 +68,9 @@ private:
     int shape_box(const rt_shape_ref& r, Aabb& out);
     uint32_t prim_count(const rt_shape_ref& r);
     uint32_t mesh_bvh(uint32_t mesh, uint32_t rank_base);
+    void build_mesh_part(uint32_t mesh, int par, BvhPart& part) const;
+    void prebuild_mesh_parts();
+    std::vector<BvhPart> mesh_part_;
     void quantize_nodes();
     void emit_shape(const rt_shape_ref& r, uint32_t item, uint32_t rank_base);
     void emit_mesh(uint32_t mesh, uint32_t item, uint32_t rank_base);

@@ -6,6 +6,7 @@
 // the triangle BVH against the oracle without a GPU.  It is not part of librt_amd.so and the
 // product never loads it.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -150,6 +151,7 @@ int emul_bvh_dump(const rt_scene_desc* d, uint32_t which, float* out, int cap_no
     H.textures.assign(d->textures, d->textures + d->num_textures);
     H.lights.assign(d->lights, d->lights + d->num_lights);
     H.ambient = d->ambient;
+    H.force_reference_scan = getenv("EMUL_REFERENCE_SCAN") != nullptr;
     if (H.build() != 0 || which >= H.bvhs.size()) { g_err = H.error; return -1; }
     std::vector<HostScene::RefNode> N;
     if (H.reference_hierarchy(H.bvhs[which], N) != 0) return -1;

@@ -80,3 +80,37 @@ def test_bmp_writer(tmp_path):
     assert b[:2] == b"BM" and len(b) == 54 + 3 * 16   # rows padded to 4 bytes (stb_image_write.h:470-477)
     top_row = b[54 + 2 * 16: 54 + 3 * 16]              # bottom-up file order: image row 0 is last
     assert list(top_row[:3]) == [63, 127, 255]          # BGR, truncating conversion
+
+
+def test_fast_pairing_equals_reference_scan(emul):
+    """The O(n^2 log n) sorted-pair form of BVHAccel::generateBVH's greedy pairing (rt_scene.cpp) must
+    build the same hierarchy as the reference's own O(n^3) scan, ties included: 21 x 19 spheres on an
+    integer lattice (most centroid distances occur many times), then the same with jittered centres."""
+    import os
+    import numpy as np
+    from raytracer_amd import scene as S
+    rng = np.random.default_rng(3)
+    for jitter in (0.0, 0.4):
+        w = S.World()
+        w.width, w.height = 16, 16
+        w.sampler = S.Regular(1, 1)
+        mat = S.Matte()
+        bvh = S.BVHAccel()
+        for y in range(19):
+            for x in range(21):
+                c = (float(x) + jitter * rng.random(), float(y) + jitter * rng.random(), float((x * y) % 3))
+                bvh.addShape(S.Sphere(c, 0.3).setMaterial(mat))
+        bvh.generateBVH()
+        w.scene = [bvh]
+        w.ambient = S.Ambient(0, 1000.0)
+        w.lights = []
+        w.camera = S.Camera((0, 0, 50), (10, 10, 0), (0, 1, 0), 20.0)
+        flat = w.flatten()
+        fast = emul.bvh_dump(flat, cap=2048)
+        os.environ["EMUL_REFERENCE_SCAN"] = "1"
+        try:
+            slow = emul.bvh_dump(flat, cap=2048)
+        finally:
+            del os.environ["EMUL_REFERENCE_SCAN"]
+        assert len(fast) >= 2 * 399 - 1
+        assert fast.shape == slow.shape and np.array_equal(fast.view(np.uint32), slow.view(np.uint32))
