@@ -105,6 +105,12 @@ def test_tile_split_matches_full_frame(emul):
     assert util.bits_equal(acc, full)
 
 
+def test_more_meshes_on_a_ray_than_deferred_roots(emul, port):
+    w = util.mesh_tunnel_scene()
+    cnt, want = check(emul, port, w, w.params(seed=5), min_exact=0.90)
+    assert (want.primid != capi.RT_MISS).mean() > 0.5
+
+
 def test_gate_classification_is_sound(emul):
     """gate_maybe == False must imply the reference box test fails, gate_surely == True that it
     passes (rt_core.hpp); 4 M random + adversarial rays (edges, corners, planes, tiny components)."""

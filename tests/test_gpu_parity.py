@@ -226,3 +226,11 @@ def test_bvh_queue_overflow_falls_back_inline(gpu):
         del os.environ["RT_DEBUG"]
         gpu.upload(world)
     assert np.array_equal(gid, wid) and util.bits_equal(gt, wt) and util.bits_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_more_meshes_on_a_ray_than_deferred_roots(gpu, port):
+    """Rays that pass the gates of 14 meshes: more than the 8 roots a queue item carries, so the walk
+    drains inline in mid-walk and queues the rest."""
+    w = util.mesh_tunnel_scene(96, 72)
+    test_matches_oracle(gpu, port, "mesh_tunnel", w, w.params(seed=5))

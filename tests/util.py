@@ -78,3 +78,35 @@ def small_scenes():
     w = scenes.config5_scene(64, 36, spp=1, instances=9, mesh_nu=12, mesh_nv=8)
     out.append(("config5_instanced", w, w.params(seed=5)))
     return out
+
+
+def mesh_tunnel_scene(width=64, height=48, meshes=14):
+    """A row of `meshes` nested / overlapping tori along the view direction plus free triangles and a
+    lone Mesh: primary and AO rays pass the box gates of more than RT_DEFER_ROOTS (8) meshes, so the
+    gate walk has to drain deferred roots inline in mid-walk (rt_core.hpp trace())."""
+    from raytracer_amd import scenes, scene as S
+    w = S.World()
+    w.width, w.height = width, height
+    w.sampler = S.Jitter(4, 5)
+    tex = scenes.checker_texture()
+    mats = []
+    for k in range(3):
+        m = S.Textured(tex); m.setAmbientReflection(0.4 + 0.2 * k)
+        mats.append(m)
+    shapes = []
+    for k in range(meshes):
+        obj = scenes.torus_objmesh(mats[k % 3], 12, 6, R=40.0 + 3.0 * (k % 4), r=10.0, centre=(0.0, 0.0, 0.0))
+        shapes.append(S.MultiMesh(obj, "teapot", (4.0 * (k % 3), 2.0 * (k % 2), -60.0 * k)))
+    spec = S.Specular(); spec.setDiffuseColour((0.8, 0.3, 0.2))
+    floor = S.Plane((0, -70, 0), (0, 1, 0)).setMaterial(spec)
+    bvh = S.BVHAccel()
+    for s in shapes[: meshes // 2]:
+        bvh.addShape(s)
+    bvh.generateBVH()
+    w.scene = [floor, bvh] + shapes[meshes // 2:]
+    w.ambient = S.Ambient(2, 1000.0)
+    w.ambient.setColour((1, 1, 1)); w.ambient.scaleRadiance(0.5)
+    light = S.PointLight((100, 300, 200)); light.setColour((1, 1, 1)); light.scaleRadiance(1.0)
+    w.lights = [light]
+    w.camera = S.Camera((2, 1, 160), (2, 1, -400), (0, 1, 0), 60.0 * height / 48.0)
+    return w
