@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B
 #define RT_REFILL_IDLE 32    // refill once this many lanes hold no ray
 #endif
 #ifndef RT_PEND
-#define RT_PEND 3            // parked leaves per lane
+#define RT_PEND 2            // parked leaves per lane
 #endif
 #ifndef RT_NODE_REPS
 #define RT_NODE_REPS 4       // steps of one kind per vote (see the vote below)

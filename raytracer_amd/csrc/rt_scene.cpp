@@ -225,11 +225,12 @@ uint32_t HostScene::add_triangle_slot(uint32_t gid, uint32_t rank)
     return slot;
 }
 
-// ---- triangle BVH of one Mesh: binned SAH, <= 4 triangles per leaf, two-child nodes (built as 64-byte
+// ---- triangle BVH of one Mesh: binned SAH, <= 2 triangles per leaf, two-child nodes (built as 64-byte
 //      float nodes, shipped as 32-byte quantised nodes: quantize_nodes) ----
 namespace {
 struct BuildTri { float mn[3], mx[3], c[3]; uint32_t gid; };
-constexpr uint32_t kLeafMax = 4;
+// triangles per leaf: 2 (best of 1..8 measured on config 3: fewer exact tests outweigh the extra nodes); RT_LEAF_MAX overrides it for such measurements
+static const uint32_t kLeafMax = [] { const char* e = getenv("RT_LEAF_MAX"); int v = e ? atoi(e) : 2; return (uint32_t)(v < 1 ? 1 : v > 8 ? 8 : v); }();
 constexpr int kMaxDepth = 24;   // inner-node depth bound: RT_STACK_DEPTH (32) = RT_DEFER_ROOTS (8) pending roots + this
 constexpr int kBins = 16;
 
