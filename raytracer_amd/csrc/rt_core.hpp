@@ -259,6 +259,12 @@ struct RayCull { float sx, sy, sz, lx, ly, lz, hx, hy, hz; };
 
 // Node boxes are 16-bit grid indices q (coordinate = qbase + q*qscale, rounded outwards by the
 // builder), so the slab distances are affine in q: t = q * (qscale/d) + (qbase - o -+ pad)/d.
+// Two margins are folded into the per-ray constants, so the per-node test is bare min/max/compare:
+//  * pad (space): the lower planes move by -pad, the upper ones by +pad;
+//  * E (parameter): a bound on the rounding of q*s + l itself, 2^-18 * (65535|s| + |l| + |h|) per axis
+//    (the true bound is ~2^-22 of that sum: approximate reciprocal, two products, one fma), subtracted
+//    from the axis' entry distance and added to its exit distance (which plane is which follows from
+//    the sign of d).
 RT_FN RayCull make_cull(const DScene& S, f3 o, f3 d)
 {
     RayCull c;
@@ -266,13 +272,21 @@ RT_FN RayCull make_cull(const DScene& S, f3 o, f3 d)
     float dx = fabsf(d.x) > 1e-20f ? d.x : (d.x < 0 ? -1e-20f : 1e-20f);
     float dy = fabsf(d.y) > 1e-20f ? d.y : (d.y < 0 ? -1e-20f : 1e-20f);
     float dz = fabsf(d.z) > 1e-20f ? d.z : (d.z < 0 ? -1e-20f : 1e-20f);
-    // approximate reciprocals are enough: their 1-ulp error is inside cull_box's relative slack
+    // approximate reciprocals are enough: their 1-ulp error is inside E
     float ix = approx_rcp(dx), iy = approx_rcp(dy), iz = approx_rcp(dz);
     float bx = S.qbase.x - o.x, by = S.qbase.y - o.y, bz = S.qbase.z - o.z;
     c.sx = S.qscale.x * ix; c.sy = S.qscale.y * iy; c.sz = S.qscale.z * iz;
     c.lx = (bx - pad) * ix; c.hx = (bx + pad) * ix;
     c.ly = (by - pad) * iy; c.hy = (by + pad) * iy;
     c.lz = (bz - pad) * iz; c.hz = (bz + pad) * iz;
+    const float k = 1.0f / 262144.0f;
+    float ex = k * (65535.0f * fabsf(c.sx) + fabsf(c.lx) + fabsf(c.hx));
+    float ey = k * (65535.0f * fabsf(c.sy) + fabsf(c.ly) + fabsf(c.hy));
+    float ez = k * (65535.0f * fabsf(c.sz) + fabsf(c.lz) + fabsf(c.hz));
+    // d > 0: the lower plane is the entry (earlier by E), the upper one the exit (later by E); d < 0: the reverse
+    c.lx -= ix >= 0 ? ex : -ex; c.hx += ix >= 0 ? ex : -ex;
+    c.ly -= iy >= 0 ? ey : -ey; c.hy += iy >= 0 ? ey : -ey;
+    c.lz -= iz >= 0 ? ez : -ez; c.hz += iz >= 0 ? ez : -ez;
     return c;
 }
 
@@ -288,9 +302,7 @@ RT_FN bool cull_box(const RayCull& c, float mnx, float mny, float mnz, float mxx
     float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     float f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     tnear = n;
-    // widen by a relative slack for the rounding of the slab arithmetic itself
-    float slack = 4e-6f * fmaxf(fabsf(n), fabsf(f));
-    return (n - slack <= f + slack) && (n - slack <= tbest);
+    return n <= f && n <= tbest;
 }
 
 // both child boxes of a 32-byte node {w0..w3}{w4,w5,ref0,ref1}: w = lo | hi<<16 over the sequence
@@ -298,8 +310,8 @@ RT_FN bool cull_box(const RayCull& c, float mnx, float mny, float mnz, float mxx
 RT_FN void node_test(const RayCull& rc, q4 n0, q4 n1, float tbest, bool& h0, bool& h1, float& t0, float& t1, uint32_t& r0, uint32_t& r1)
 {
     r0 = f2u(n1.z); r1 = f2u(n1.w);
-    h0 = cull_box(rc, q_lo(n0.x), q_hi(n0.x), q_lo(n0.y), q_hi(n0.y), q_lo(n0.z), q_hi(n0.z), tbest, t0) && r0 != REF_NONE;
-    h1 = cull_box(rc, q_lo(n0.w), q_hi(n0.w), q_lo(n1.x), q_hi(n1.x), q_lo(n1.y), q_hi(n1.y), tbest, t1) && r1 != REF_NONE;
+    h0 = cull_box(rc, q_lo(n0.x), q_hi(n0.x), q_lo(n0.y), q_hi(n0.y), q_lo(n0.z), q_hi(n0.z), tbest, t0);
+    h1 = cull_box(rc, q_lo(n0.w), q_hi(n0.w), q_lo(n1.x), q_hi(n1.x), q_lo(n1.y), q_hi(n1.y), tbest, t1);
 }
 
 template <bool STATS, bool ANYHIT>

@@ -379,9 +379,11 @@ void HostScene::build_mesh_part(uint32_t mesh, int par, BvhPart& part) const
         for (auto& b : T) part.order.push_back(b.gid);
         const uint32_t leaf = REF_LEAF | ((m.num_triangles - 1u) << 28) | 0u;
         part.nodes.push_back({mn[0], mn[1], mn[2], mx[0]});
+        // every node has two valid children (the traversal does not test for absent ones): the second
+        // child is the same leaf behind a box that quantises to one grid point; entering it repeats a test, no more
         part.nodes.push_back({mx[1], mx[2], INFINITY, INFINITY});
         part.nodes.push_back({INFINITY, -INFINITY, -INFINITY, -INFINITY});
-        part.nodes.push_back({u2f(leaf), u2f((uint32_t)REF_NONE), 0.0f, 0.0f});
+        part.nodes.push_back({u2f(leaf), u2f(leaf), 0.0f, 0.0f});
         part.root = 0;
     } else {
         part.root = build_subtree(T, 0, m.num_triangles, 0, par, part);
@@ -441,8 +443,8 @@ void HostScene::quantize_nodes()
     };
     for (size_t i = 0; i < n; ++i)
         for (int c = 0; c < 2; ++c) {
-            if (f2u((&fnodes4[i * 4 + 3].x)[c]) == REF_NONE) continue;
             float lo[3], hi[3]; box_of(i, c, lo, hi);
+            if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) continue;   // the inverted box of a one-leaf root
             for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], lo[a]); mx[a] = std::max(mx[a], hi[a]); }
         }
     for (int a = 0; a < 3; ++a) {
@@ -454,9 +456,9 @@ void HostScene::quantize_nodes()
     for (size_t i = 0; i < n; ++i) {
         uint32_t q[12] = {0};
         for (int c = 0; c < 2; ++c) {
-            if (f2u((&fnodes4[i * 4 + 3].x)[c]) == REF_NONE) continue;
             float lo[3], hi[3]; box_of(i, c, lo, hi);
             for (int a = 0; a < 3; ++a) {
+                if (!(lo[a] <= hi[a])) { q[c * 6 + a] = 0; q[c * 6 + 3 + a] = 0; continue; }   // the dummy child: a point box at the grid origin
                 double l = std::floor(((double)lo[a] - (double)qbase[a]) / (double)qscale[a]) - 1.0;
                 double h = std::ceil(((double)hi[a] - (double)qbase[a]) / (double)qscale[a]) + 1.0;
                 uint32_t ql = (uint32_t)std::min(65535.0, std::max(0.0, l)), qh = (uint32_t)std::min(65535.0, std::max(0.0, h));
