@@ -167,7 +167,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
 {
     __shared__ uint32_t s_stack[RT_LDS_STACK * RT_BLOCK];
     __shared__ uint32_t s_pend[RT_PEND * RT_BLOCK];
-    uint32_t* const spill = B.bq_spill + (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    // volatile: keeps the (rare) global spill accesses from being merged with the LDS ones into
+    // generic-pointer (flat) instructions, which wait on both memory counters
+    volatile uint32_t* const spill = B.bq_spill + (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;
     const size_t spill_stride = (size_t)RT_MAX_GRID * RT_BLOCK;
     auto push = [&](uint32_t& sp_, uint32_t x) {
         if (sp_ < RT_LDS_STACK) s_stack[sp_ * RT_BLOCK + threadIdx.x] = x;
@@ -177,8 +179,6 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
     };
     auto pop = [&](uint32_t& sp_) -> uint32_t {
         --sp_;
-        // the LDS read is unconditional (clamped) so that the two sources stay two instructions
-        // instead of one generic-pointer (flat) load
         uint32_t x = s_stack[(sp_ < RT_LDS_STACK ? sp_ : RT_LDS_STACK - 1) * RT_BLOCK + threadIdx.x];
         if (sp_ >= RT_LDS_STACK) x = spill[(size_t)(sp_ - RT_LDS_STACK) * spill_stride];
         return x;
