@@ -1,6 +1,7 @@
 // rt_scene.cpp — validation, reference-structure rebuild and triangle-BVH construction.
 #include "rt_scene.hpp"
 #include <atomic>
+#include <mutex>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -180,15 +181,24 @@ int HostScene::reference_hierarchy(const rt_bvh& b, std::vector<RefNode>& H)
                     if (dist < std::numeric_limits<float>::max()) pairs.push_back(Pair{dist, i, k});
                 }
             }
-            std::sort(pairs.begin(), pairs.end(), [](const Pair& a, const Pair& b) {
+            auto before = [](const Pair& a, const Pair& b) {
                 if (a.dist != b.dist) return a.dist < b.dist;
                 if (a.i != b.i) return a.i > b.i;
                 return a.k > b.k;
-            });
-            for (const Pair& p : pairs) {
-                if (made == next_layer) break;
-                if (H[p.i].accessed || H[p.k].accessed) continue;
-                join(p.i, p.k); ++made;
+            };
+            // most nodes find their partner among the few closest pairs: sort the list in growing
+            // chunks (selection + sort of the chunk) instead of all of it
+            size_t unpaired = layer;
+            for (size_t done = 0, chunk = 8 * layer; done < pairs.size() && made < next_layer && unpaired > 1; chunk *= 4) {
+                const size_t end_c = std::min(pairs.size(), done + chunk);
+                if (end_c < pairs.size()) std::nth_element(pairs.begin() + done, pairs.begin() + end_c, pairs.end(), before);
+                std::sort(pairs.begin() + done, pairs.begin() + end_c, before);
+                for (size_t x = done; x < end_c && made < next_layer; ++x) {
+                    const Pair& p = pairs[x];
+                    if (H[p.i].accessed || H[p.k].accessed) continue;
+                    join(p.i, p.k); ++made; unpaired -= 2;
+                }
+                done = end_c;
             }
             for (; made < next_layer; ++made) copy_up();
         }
@@ -214,16 +224,36 @@ int HostScene::reference_hierarchy(const rt_bvh& b, std::vector<RefNode>& H)
     return RT_OK;
 }
 
-uint32_t HostScene::add_triangle_slot(uint32_t gid, uint32_t rank)
+void HostScene::write_triangle_slot(uint32_t slot, uint32_t gid, uint32_t rank)
 {
     const rt_triangle& t = triangles[gid];
+    tris4[(size_t)slot * 3 + 0] = {t.v0[0], t.v0[1], t.v0[2], u2f(gid)};
+    tris4[(size_t)slot * 3 + 1] = {t.v1[0] - t.v0[0], t.v1[1] - t.v0[1], t.v1[2] - t.v0[2], u2f((uint32_t)t.material)};
+    tris4[(size_t)slot * 3 + 2] = {t.v2[0] - t.v0[0], t.v2[1] - t.v0[1], t.v2[2] - t.v0[2], u2f(rank)};
+}
+
+uint32_t HostScene::add_triangle_slot(uint32_t gid, uint32_t rank)
+{
     uint32_t slot = (uint32_t)(tris4.size() / 3);
-    q4 a = {t.v0[0], t.v0[1], t.v0[2], u2f(gid)};
-    q4 b = {t.v1[0] - t.v0[0], t.v1[1] - t.v0[1], t.v1[2] - t.v0[2], u2f((uint32_t)t.material)};
-    q4 c = {t.v2[0] - t.v0[0], t.v2[1] - t.v0[1], t.v2[2] - t.v0[2], u2f(rank)};
-    tris4.push_back(a); tris4.push_back(b); tris4.push_back(c);
+    tris4.resize(tris4.size() + 3);
+    write_triangle_slot(slot, gid, rank);
     return slot;
 }
+
+namespace {
+// fn(begin, end) over [0, n) on up to 16 threads (the calling thread included)
+template <class F>
+void parallel_ranges(size_t n, size_t min_chunk, F fn)
+{
+    const size_t hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const size_t nt = std::max<size_t>(1, std::min(hw, n / std::max<size_t>(1, min_chunk)));
+    if (nt <= 1) { fn((size_t)0, n); return; }
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < nt; ++t) pool.emplace_back([=] { fn(n * t / nt, n * (t + 1) / nt); });
+    fn((size_t)0, n / nt);
+    for (auto& t : pool) t.join();
+}
+} // namespace
 
 // ---- triangle BVH of one Mesh: binned SAH, <= 2 triangles per leaf, two-child nodes (built as 64-byte
 //      float nodes, shipped as 32-byte quantised nodes: quantize_nodes) ----
@@ -415,18 +445,44 @@ uint32_t HostScene::mesh_bvh(uint32_t mesh, uint32_t rank_base)
     if (mesh_root_[mesh] != 0xFFFFFFFFu && mesh_rank_[mesh] == rank_base) return mesh_root_[mesh];
     const rt_mesh& m = meshes[mesh];
     const BvhPart& part = mesh_part_[mesh];
+    // reserve this occurrence's node and slot ranges now (the layout is that of a sequential build); the
+    // copies themselves run on all threads after the emission pass (run_append_jobs)
     const uint32_t node_off = (uint32_t)(fnodes4.size() / 4), slot_off = (uint32_t)(tris4.size() / 3);
-    for (size_t i = 0; i + 3 < part.nodes.size(); i += 4) {
-        fnodes4.push_back(part.nodes[i]); fnodes4.push_back(part.nodes[i + 1]); fnodes4.push_back(part.nodes[i + 2]);
-        q4 r = part.nodes[i + 3];
-        r.x = u2f(relocate(f2u(r.x), node_off, slot_off)); r.y = u2f(relocate(f2u(r.y), node_off, slot_off));
-        fnodes4.push_back(r);
-    }
-    for (uint32_t gid : part.order) add_triangle_slot(gid, rank_base + (gid - m.first_triangle));
+    fnodes4.resize(fnodes4.size() + part.nodes.size());
+    tris4.resize(tris4.size() + 3 * part.order.size());
+    append_jobs_.push_back(AppendJob{mesh, rank_base, node_off, slot_off});
     const uint32_t root = relocate(part.root, node_off, slot_off);
     bvh_max_depth = std::max(bvh_max_depth, part.max_depth);
     mesh_root_[mesh] = root; mesh_rank_[mesh] = rank_base;
     return root;
+}
+
+void HostScene::run_append_jobs()
+{
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (size_t j; (j = next.fetch_add(1)) < append_jobs_.size();) {
+            const AppendJob& job = append_jobs_[j];
+            const BvhPart& part = mesh_part_[job.mesh];
+            const uint32_t first = meshes[job.mesh].first_triangle;
+            q4* dst = &fnodes4[(size_t)job.node_off * 4];
+            for (size_t i = 0; i + 3 < part.nodes.size(); i += 4) {
+                dst[i] = part.nodes[i]; dst[i + 1] = part.nodes[i + 1]; dst[i + 2] = part.nodes[i + 2];
+                q4 r = part.nodes[i + 3];
+                r.x = u2f(relocate(f2u(r.x), job.node_off, job.slot_off)); r.y = u2f(relocate(f2u(r.y), job.node_off, job.slot_off));
+                dst[i + 3] = r;
+            }
+            for (size_t k = 0; k < part.order.size(); ++k)
+                write_triangle_slot(job.slot_off + (uint32_t)k, part.order[k], job.rank_base + (part.order[k] - first));
+        }
+    };
+    // one big mesh: split by hand would be needed to go faster; many meshes: one job each
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < std::min<size_t>(hw, append_jobs_.size()); ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    append_jobs_.clear();
 }
 
 // 64-byte float nodes -> 32-byte nodes: the 12 box coordinates become 16-bit grid indices in ONE frame
@@ -441,19 +497,26 @@ void HostScene::quantize_nodes()
         const float* f = &fnodes4[i * 4].x;
         for (int a = 0; a < 3; ++a) { lo[a] = f[child * 6 + a]; hi[a] = f[child * 6 + 3 + a]; }
     };
-    for (size_t i = 0; i < n; ++i)
-        for (int c = 0; c < 2; ++c) {
-            float lo[3], hi[3]; box_of(i, c, lo, hi);
-            if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) continue;   // the inverted box of a one-leaf root
-            for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], lo[a]); mx[a] = std::max(mx[a], hi[a]); }
-        }
+    std::mutex mu;
+    parallel_ranges(n, 1 << 16, [&](size_t b, size_t e) {
+        float tmn[3] = {INFINITY, INFINITY, INFINITY}, tmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t i = b; i < e; ++i)
+            for (int c = 0; c < 2; ++c) {
+                float lo[3], hi[3]; box_of(i, c, lo, hi);
+                if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) continue;   // the inverted box of a one-leaf root
+                for (int a = 0; a < 3; ++a) { tmn[a] = std::min(tmn[a], lo[a]); tmx[a] = std::max(tmx[a], hi[a]); }
+            }
+        std::lock_guard<std::mutex> lk(mu);
+        for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], tmn[a]); mx[a] = std::max(mx[a], tmx[a]); }
+    });
     for (int a = 0; a < 3; ++a) {
         if (!(mn[a] <= mx[a])) { mn[a] = 0.0f; mx[a] = 1.0f; }
         qbase[a] = mn[a];
         qscale[a] = std::max((mx[a] - mn[a]) / 65533.0f, 1e-30f);
     }
     nodes4.assign(n * 2, q4{0, 0, 0, 0});
-    for (size_t i = 0; i < n; ++i) {
+    parallel_ranges(n, 1 << 16, [&](size_t b, size_t e) {
+    for (size_t i = b; i < e; ++i) {
         uint32_t q[12] = {0};
         for (int c = 0; c < 2; ++c) {
             float lo[3], hi[3]; box_of(i, c, lo, hi);
@@ -473,6 +536,7 @@ void HostScene::quantize_nodes()
         nodes4[i * 2 + 0] = {u2f(w[0]), u2f(w[1]), u2f(w[2]), u2f(w[3])};
         nodes4[i * 2 + 1] = {u2f(w[4]), u2f(w[5]), fnodes4[i * 4 + 3].x, fnodes4[i * 4 + 3].y};
     }
+    });
 }
 
 void HostScene::emit_mesh(uint32_t mesh, uint32_t item, uint32_t rank_base)
@@ -487,7 +551,9 @@ void HostScene::emit_mesh(uint32_t mesh, uint32_t item, uint32_t rank_base)
 int HostScene::emit_bvh(uint32_t bvh, uint32_t item, uint32_t rank_base)
 {
     std::vector<RefNode> H;
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = reference_hierarchy(bvhs[bvh], H);
+    hierarchy_seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (rc) return rc;
     const uint32_t root = (uint32_t)H.size() - 1;
     // ranks follow the reference's breadth-first visiting order (BVHAccel::hit, main.cpp:425-470)
@@ -573,6 +639,8 @@ int HostScene::build()
     gates.clear(); planes4.clear(); spheres4.clear(); tris4.clear(); attr4.clear(); nodes4.clear(); fnodes4.clear();
     dmaterials.clear(); dlights.clear(); dtextures.clear(); texels.clear(); item_opaque.clear();
     bvh_max_depth = 0;
+    append_jobs_.clear();
+    hierarchy_seconds_ = 0.0;
 
     // Mesh / MultiMesh gate boxes (main.cpp:875-881, 757-765)
     mesh_box_.assign(meshes.size(), Aabb{});
@@ -607,10 +675,25 @@ int HostScene::build()
         spheres4.push_back({s.radius * s.radius, u2f((uint32_t)s.material), 0.0f, 0.0f});   // mRadiusSqr{radius*radius}
     }
     extent = 1.0f;
-    for (auto& t : triangles) {
-        attr4.push_back({t.uv0[0], t.uv0[1], t.uv1[0], t.uv1[1]});
-        attr4.push_back({t.uv2[0], t.uv2[1], 0.0f, 0.0f});
-        for (int k = 0; k < 3; ++k) extent = std::max(extent, std::max(std::fabs(t.v0[k]), std::max(std::fabs(t.v1[k]), std::fabs(t.v2[k]))));
+    attr4.resize(triangles.size() * 2);
+    {
+        std::mutex mu;
+        parallel_ranges(triangles.size(), 1 << 16, [&](size_t b, size_t e) {
+            float ext = 1.0f;
+            for (size_t i = b; i < e; ++i) {
+                const rt_triangle& t = triangles[i];
+                attr4[i * 2] = {t.uv0[0], t.uv0[1], t.uv1[0], t.uv1[1]};
+                attr4[i * 2 + 1] = {t.uv2[0], t.uv2[1], 0.0f, 0.0f};
+                for (int k = 0; k < 3; ++k) ext = std::max(ext, std::max(std::fabs(t.v0[k]), std::max(std::fabs(t.v1[k]), std::fabs(t.v2[k]))));
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            extent = std::max(extent, ext);
+        });
+    }
+    {   // one growth step instead of many: every mesh is normally reached once
+        size_t nn = 0, ns = 0;
+        for (auto& part : mesh_part_) { nn += part.nodes.size(); ns += part.order.size(); }
+        fnodes4.reserve(nn); tris4.reserve(3 * (ns + 64));
     }
 
     // gate nodes in scene order; ranks = the reference's visiting order
@@ -646,11 +729,14 @@ int HostScene::build()
         }
     }
     if (bvh_max_depth > (uint32_t)kMaxDepth + 1) { error = "triangle BVH deeper than the traversal stack"; return RT_ERR_UNSUPPORTED; }
+    const auto t_walk = now();
+    run_append_jobs();
     const auto t_emit = now();
     quantize_nodes();
     mesh_part_.clear(); mesh_part_.shrink_to_fit();
-    if (timing) std::fprintf(stderr, "[rt_scene] triangle BVHs %.3f s, gate emission (reference hierarchy, appends) %.3f s, node quantisation %.3f s\n",
-                             secs(t_begin, t_parts), secs(t_parts, t_emit), secs(t_emit, now()));
+    if (timing) std::fprintf(stderr, "[rt_scene] reference hierarchies alone %.3f s\n", hierarchy_seconds_);
+    if (timing) std::fprintf(stderr, "[rt_scene] triangle BVHs %.3f s, gate emission (reference hierarchies) %.3f s, node / triangle record copies %.3f s, node quantisation %.3f s\n",
+                             secs(t_begin, t_parts), secs(t_parts, t_walk), secs(t_walk, t_emit), secs(t_emit, now()));
 
     has_bounce_materials = false;
     for (auto& m : materials) {

@@ -71,6 +71,11 @@ private:
     void build_mesh_part(uint32_t mesh, int par, BvhPart& part) const;
     void prebuild_mesh_parts();
     std::vector<BvhPart> mesh_part_;
+    struct AppendJob { uint32_t mesh, rank_base, node_off, slot_off; };
+    std::vector<AppendJob> append_jobs_;
+    void run_append_jobs();
+    double hierarchy_seconds_ = 0.0;
+    void write_triangle_slot(uint32_t slot, uint32_t gid, uint32_t rank);
     void quantize_nodes();
     void emit_shape(const rt_shape_ref& r, uint32_t item, uint32_t rank_base);
     void emit_mesh(uint32_t mesh, uint32_t item, uint32_t rank_base);
