@@ -420,7 +420,14 @@ RT_FN f3 ambient_L(const DScene& S, const Batch& B, uint32_t p)
     float maxSum = (dist * (float)n * (float)n);
     float occluded = maxSum;
     const float* t = B.ao_t + (size_t)slot * n * n;
-    for (unsigned k = 0; k < n * n; ++k) occluded -= (dist - t[k]);
+    if (n == 4) {   // the reference's setting: four 16-byte loads in flight, then the same sequential sum
+        const q4* t4 = reinterpret_cast<const q4*>(t);   // slot * 16 floats: 64-byte aligned
+        const q4 a = t4[0], b = t4[1], c = t4[2], e = t4[3];
+        const float v[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, e.x, e.y, e.z, e.w};
+        for (int k = 0; k < 16; ++k) occluded -= (dist - v[k]);
+    } else {
+        for (unsigned k = 0; k < n * n; ++k) occluded -= (dist - t[k]);
+    }
     float f = occluded / maxSum;
     return base * f * f;
 }
