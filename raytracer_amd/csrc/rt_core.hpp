@@ -73,6 +73,7 @@ struct DMaterial { int32_t kind; float colour[3]; float kd, ka, ks; int32_t spec
 struct DLight { int32_t kind; float v[3]; float colour[3]; float radiance; };
 struct DTexture { uint32_t offset; int32_t width, height; int32_t set; };
 
+#define RT_LEAD_PLANES 8
 struct DScene {
     const GateNode* gates; uint32_t num_gates;
     const GateNode* gates_fast; uint32_t num_gates_fast;   // GPU: the first nodes staged in LDS by the kernel (0 = none)
@@ -91,6 +92,11 @@ struct DScene {
     float cull_pad;      // conservative padding of the BVH culling test, relative (see bvh_traverse)
     float extent;        // largest |coordinate| of the scene
     uint32_t debug;      // experiment switches (0 in production)
+    // The gate array's leading run of top-level Plane nodes (the room of the reference's scenes), by value:
+    // kernel arguments sit in constant memory, so a closest-hit walk reads them with scalar loads in a
+    // wave-uniform loop instead of interpreting gate nodes.  {point, normal, bits(rank), bits(plane index)}
+    uint32_t num_lead_planes;
+    float lead_planes[RT_LEAD_PLANES][8];
 };
 
 // BVH child reference: bit31 = leaf, bits 28..30 = triangle count-1, bits 0..27 = first slot
@@ -407,6 +413,16 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
     uint32_t cur_item = 0;
     uint32_t i = 0, sp = 0;
     const uint32_t n = S.num_gates;
+    if (MODE == 0) {   // the shadow query keeps per-entry state: it walks these nodes like any other
+        for (uint32_t j = 0; j < S.num_lead_planes; ++j) {
+            const float* pl = S.lead_planes[j];
+            float t;
+            if (plane_t(F3(pl[0], pl[1], pl[2]), F3(pl[3], pl[4], pl[5]), o, d, t) && closer(t, f2u(pl[6]), best)) {
+                best.t = t; best.prim = H_PLANE | f2u(pl[7]); best.rank = f2u(pl[6]);
+            }
+        }
+        i = S.num_lead_planes;
+    }
     while (i < n) {
         const GateNode g = load_gate(S, i);
         if (MODE == 1 && g.item != cur_item) {

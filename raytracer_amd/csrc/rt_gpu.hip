@@ -724,6 +724,7 @@ int rt_scene_commit(rt_scene* s)
     D.cull_pad = 1.0f / 262144.0f;
     D.extent = H.extent;
     D.qbase = F3(H.qbase[0], H.qbase[1], H.qbase[2]); D.qscale = F3(H.qscale[0], H.qscale[1], H.qscale[2]);
+    H.fill_lead_planes(D);
     D.debug = getenv("RT_DEBUG") ? (uint32_t)atoi(getenv("RT_DEBUG")) : 0u;
     s->committed = true;
     return RT_OK;

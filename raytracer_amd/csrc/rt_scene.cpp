@@ -631,6 +631,18 @@ bool HostScene::subtree_opaque(const rt_shape_ref& r)
     return false;
 }
 
+void HostScene::fill_lead_planes(DScene& D) const
+{
+    D.num_lead_planes = 0;
+    for (size_t i = 0; i < gates.size() && i < RT_LEAD_PLANES; ++i) {
+        const GateNode& g = gates[i];
+        if ((g.kind & G_KIND_MASK) != G_PLANE) break;   // top-level nodes come first; a plane inside a BVHAccel follows a gated node
+        float* pl = D.lead_planes[D.num_lead_planes++];
+        std::memcpy(pl, g.mn, 12); std::memcpy(pl + 3, g.mx, 12);
+        pl[6] = u2f(g.rank); pl[7] = u2f(g.a);
+    }
+}
+
 int HostScene::build()
 {
     error.clear();

@@ -43,6 +43,7 @@ struct HostScene {
     float extent = 0.0f;
     bool has_bounce_materials = false;
     uint32_t bvh_max_depth = 0;
+    void fill_lead_planes(DScene& D) const;   // the leading top-level Plane nodes of `gates`, for DScene::lead_planes
 
     std::string error;
 

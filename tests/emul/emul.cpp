@@ -93,6 +93,7 @@ int emul_render(const rt_scene_desc* d, const rt_camera* cam, const rt_params* p
     S.ambient = H.ambient;
     S.prim_base_sphere = (uint32_t)H.planes.size(); S.prim_base_tri = (uint32_t)(H.planes.size() + H.spheres.size());
     S.cull_pad = 1.0f / 262144.0f; S.extent = H.extent; S.debug = 0;
+    H.fill_lead_planes(S);
     S.qbase = F3(H.qbase[0], H.qbase[1], H.qbase[2]); S.qscale = F3(H.qscale[0], H.qscale[1], H.qscale[2]);
 
     RenderArgs A{};
