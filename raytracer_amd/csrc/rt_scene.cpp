@@ -262,7 +262,9 @@ struct BuildTri { float mn[3], mx[3], c[3]; uint32_t gid; };
 // triangles per leaf: 2 (best of 1..8 measured on config 3: fewer exact tests outweigh the extra nodes); RT_LEAF_MAX overrides it for such measurements
 static const uint32_t kLeafMax = [] { const char* e = getenv("RT_LEAF_MAX"); int v = e ? atoi(e) : 2; return (uint32_t)(v < 1 ? 1 : v > 8 ? 8 : v); }();
 constexpr int kMaxDepth = 24;   // inner-node depth bound: RT_STACK_DEPTH (32) = RT_DEFER_ROOTS (8) pending roots + this
-constexpr int kBins = 16;
+constexpr int kMaxBins = 64;
+// SAH bins per axis: RT_SAH_BINS overrides the default for measurements (8..64)
+static const int kBins = [] { const char* e = getenv("RT_SAH_BINS"); int v = e ? atoi(e) : 16; return v < 2 ? 2 : v > kMaxBins ? kMaxBins : v; }();
 
 inline float half_area(const float* mn, const float* mx)
 {
@@ -317,8 +319,8 @@ uint32_t build_subtree(std::vector<BuildTri>& T, uint32_t lo, uint32_t hi, int d
     for (int a = 0; a < 3; ++a) {
         float ext = cmx[a] - cmn[a];
         if (!(ext > 0.0f)) continue;
-        uint32_t cnt[kBins] = {0};
-        float bmn[kBins][3], bmx[kBins][3];
+        uint32_t cnt[kMaxBins] = {0};
+        float bmn[kMaxBins][3], bmx[kMaxBins][3];
         for (int b = 0; b < kBins; ++b) for (int k = 0; k < 3; ++k) { bmn[b][k] = INFINITY; bmx[b][k] = -INFINITY; }
         float scale = (float)kBins / ext;
         for (uint32_t i = lo; i < hi; ++i) {
@@ -326,7 +328,7 @@ uint32_t build_subtree(std::vector<BuildTri>& T, uint32_t lo, uint32_t hi, int d
             cnt[b]++;
             for (int k = 0; k < 3; ++k) { bmn[b][k] = std::min(bmn[b][k], T[i].mn[k]); bmx[b][k] = std::max(bmx[b][k], T[i].mx[k]); }
         }
-        float rarea[kBins]; uint32_t rcnt[kBins];
+        float rarea[kMaxBins]; uint32_t rcnt[kMaxBins];
         float amn[3] = {INFINITY, INFINITY, INFINITY}, amx[3] = {-INFINITY, -INFINITY, -INFINITY};
         uint32_t c = 0;
         for (int b = kBins - 1; b > 0; --b) {
