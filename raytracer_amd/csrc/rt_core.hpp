@@ -107,7 +107,7 @@ struct Counters { uint32_t nodes, tris, gates, rays; };
 struct Stack { uint32_t* p; uint32_t stride; };  // entry i lives at p[i*stride] (LDS: stride = threads per block)
 #define RT_STACK_DEPTH 32
 #define RT_DEFER_ROOTS 8   // mesh roots one queued BVH item can carry
-#define RT_PENDING_MAX 2   // deferred mesh roots before the drain loop is forced (builder depth bound = 30)
+#define RT_PENDING_MAX 2   // deferred mesh roots before the inline drain loop is forced (builder depth bound 24 + these < RT_STACK_DEPTH)
 
 struct Hit { float t; uint32_t prim; float u, v; uint32_t rank; };
 

@@ -1,7 +1,7 @@
 // rt_pipeline.hpp — the wavefront pipeline: per-item bodies of the seven kernels and the
 // batch/depth loop that sequences them.  The item bodies are host/device functions (see
 // rt_core.hpp for why); `render_frame<Backend>` is instantiated with the HIP launcher in
-// rt_api.cpp and with a sequential loop backend in the test-only emulation (tests/emul/).
+// rt_gpu.hip and with a sequential loop backend in the test-only emulation (tests/emul/).
 //
 // Pipeline per batch of P = pixels*spp paths (reference call stack in brackets):
 //   raygen            [raytrace(): sampleUnitSquare + Camera::calculateRay, main.cpp:1633-1641]
@@ -20,6 +20,7 @@
 namespace rt {
 
 enum : uint8_t { LK_NONE = 0, LK_TERMINAL = 1, LK_MIRROR = 2, LK_REFRACT = 3 };
+// (C_AO is unused since AO work became positional: slot = path index)
 enum { C_QUEUE = 0, C_AO = 64, C_SH = 128, C_BQ = 192, C_BQA = 256, C_BQ_NEXT = 320, C_BQA_NEXT = 384, C_TOTAL = 448 };   // per-batch u32 counters, one per depth
 enum { ST_SHADOW = 0, ST_AO = 1, ST_BOUNCE = 2, ST_NODES = 3, ST_TRIS = 6, ST_GATES = 9, ST_BVHRAYS = 12, ST_TOTAL = 15 }; // u64
 #define RT_MAX_LEVELS 62
