@@ -35,13 +35,23 @@ RT_HD uint32_t rt_mix32(uint32_t x)
     return x;
 }
 
-RT_HD uint32_t rt_rand31(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t counter)
+/* rt_rand31 in two steps: the part that is the same for every counter of one primary sample ... */
+RT_HD uint32_t rt_rand31_prefix(uint32_t seed, uint32_t pixel, uint32_t sample)
 {
     uint32_t h = rt_mix32(seed + 0x9E3779B9U);
     h = rt_mix32(h ^ pixel);
-    h = rt_mix32(h ^ (sample * 0x85EBCA6BU + 0xC2B2AE35U));
-    h = rt_mix32(h ^ (counter * 0x27D4EB2FU + 0x165667B1U));
-    return h >> 1;
+    return rt_mix32(h ^ (sample * 0x85EBCA6BU + 0xC2B2AE35U));
+}
+
+/* ... and the counter step (the GPU path stores the prefix with each hit and runs only this per AO ray) */
+RT_HD uint32_t rt_rand31_finish(uint32_t prefix, uint32_t counter)
+{
+    return rt_mix32(prefix ^ (counter * 0x27D4EB2FU + 0x165667B1U)) >> 1;
+}
+
+RT_HD uint32_t rt_rand31(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t counter)
+{
+    return rt_rand31_finish(rt_rand31_prefix(seed, pixel, sample), counter);
 }
 
 #endif /* RT_RNG_H */

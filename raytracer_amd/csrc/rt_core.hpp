@@ -672,13 +672,13 @@ RT_FN void ao_frame(f3 P, f3 N, f3& o, f3& u, f3& w)
 }
 
 // Direction of AO ray k (stratum x = k / n, y = k % n) in the frame (u, w)
-RT_FN f3 ao_dir(const rt_ambient& A, f3 u, f3 w, uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t ao_call, uint32_t k)
+RT_FN f3 ao_dir(const rt_ambient& A, f3 u, f3 w, uint32_t rng_prefix, uint32_t ao_call, uint32_t k)
 {
     unsigned n = (unsigned)A.occlusion_samples;
     uint32_t x = k / n, y = k % n;
     uint32_t ctr = 2u + ao_call * 2u * n * n + k * 2u;
     float grid = 1.0f / (float)n;
-    int r0 = (int)rt_rand31(seed, pixel, sample, ctr), r1 = (int)rt_rand31(seed, pixel, sample, ctr + 1);
+    int r0 = (int)rt_rand31_finish(rng_prefix, ctr), r1 = (int)rt_rand31_finish(rng_prefix, ctr + 1);
     float sampleX = (float)x * grid + (float)((div_rand_max(r0)) * (double)grid);
     float sampleY = (float)y * grid + (float)((div_rand_max(r1)) * (double)grid);
     float r = sqrtf(1.0f - sampleX * sampleX);

@@ -34,7 +34,7 @@ struct Batch {
     uint32_t* pstate;      // bits 0..7: Ambient::L evaluations so far; bits 8..15: index of the current one
     uint32_t* queue[2];    // paths alive at depth d (d >= 1), ping-pong
     // AO work is positional: slot = position of the path in this depth's path list.  Per slot, written by
-    // k_prep: {origin, bits(pixel key)} {u, bits(sample)} {w, bits(AO call index), 0xFFFFFFFF = no AO rays}
+    // k_prep: {origin, bits(RNG prefix of the primary sample)} {u, 0} {w, bits(AO call index), 0xFFFFFFFF = no AO rays}
     q4* ao_o; q4* ao_u; q4* ao_w;
     uint32_t* ao_slot;     // per path: its slot, 0xFFFFFFFF = none
     uint32_t* sh_queue;    // p * num_lights + light
@@ -296,7 +296,7 @@ RT_FN bool prep_body(const DScene& S, const RenderArgs& A, const Batch& B, int d
             slot = idx;
             f3 ao, au, aw;
             ao_frame(P, sf.normal, ao, au, aw);
-            q4 r0 = {ao.x, ao.y, ao.z, u2f(px.key)}, r1 = {au.x, au.y, au.z, u2f(px.j)}, r2 = {aw.x, aw.y, aw.z, u2f(a)};
+            q4 r0 = {ao.x, ao.y, ao.z, u2f(rt_rand31_prefix(A.seed, px.key, px.j))}, r1 = {au.x, au.y, au.z, 0.0f}, r2 = {aw.x, aw.y, aw.z, u2f(a)};
             B.ao_o[slot] = r0; B.ao_u[slot] = r1; B.ao_w[slot] = r2;
         }
     }
@@ -398,7 +398,7 @@ RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int dep
             const q4 ro = B.ao_o[slot], ru = B.ao_u[slot];
             cnt.rays++;
             o = xyz(ro);
-            dir = ao_dir(S.ambient, xyz(ru), xyz(rw), A.seed, f2u(ro.w), f2u(ru.w), f2u(rw.w), k);
+            dir = ao_dir(S.ambient, xyz(ru), xyz(rw), f2u(ro.w), f2u(rw.w), k);
             uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
             dst = slot * n2 + k;
             sp = trace<0, STATS, true>(S, o, dir, S.ambient.occlusion_dist, h, sh, st, cnt);
