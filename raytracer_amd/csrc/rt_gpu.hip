@@ -196,6 +196,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
     bool active = false, exhausted = false;
     uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform
     uint32_t nrays = 0;
+    uint32_t dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // STATS: wave-uniform diagnostics (see ST_DIAG)
     for (;;) {
         // ---- retire finished rays -------------------------------------------------------------
         if (active && cur == REF_NONE && npend == 0 && tri_left == 0) {
@@ -222,6 +223,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
             }
             const uint32_t base = chunk_next, lim = chunk_end;
             chunk_next = base + nidle < lim ? base + nidle : lim;
+            if (STATS && AO) { dg[6]++; dg[7] += chunk_next - base; }
             if (!active) {
                 const uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                 if (idx < lim) {   // items at or beyond the chunk end are left for the next refill
@@ -253,9 +255,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
         }
         // The winner of the vote is repeated (up to RT_*_REPS steps) while RT_REP_NUM/RT_REP_DEN of its voters
         // are ready again: the retire / refill / vote code above is a third of an iteration.
+        if (STATS && AO) { dg[4]++; dg[5] += (uint32_t)__popcll(__ballot(active)); }
         if (n_node > n_tri) {
             bool cn = can_node;
             for (int rep = 0;; ++rep) {
+                if (STATS && AO) { dg[0]++; dg[1] += (uint32_t)__popcll(__ballot(cn)); }
                 if (cn) {
                     uint32_t c0 = REF_NONE, c1 = REF_NONE;
                     if (!(cur & REF_LEAF)) {
@@ -291,6 +295,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
         } else {
             bool ct = can_tri;
             for (int rep = 0;; ++rep) {
+                if (STATS && AO) { dg[2]++; dg[3] += (uint32_t)__popcll(__ballot(ct)); }
                 if (ct) {
                     if (tri_left == 0) {
                         const uint32_t ref = pend[(--npend) * RT_BLOCK];
@@ -324,6 +329,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
     if (STATS) {
         for (int off = 32; off > 0; off >>= 1) nrays += __shfl_xor(nrays, off);
         if (lane == 0) atomicAdd(&B.stats[ST_BVHRAYS + (AO ? 2 : 0)], (unsigned long long)nrays);
+        if (AO && lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&B.stats[ST_DIAG + k], (unsigned long long)dg[k]);
     }
 }
 
@@ -842,6 +848,10 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
         }
         stats->rays_primary = prim * (uint64_t)A.spp;
         stats->rays_shadow = h[ST_SHADOW]; stats->rays_ao = h[ST_AO]; stats->rays_bounce = h[ST_BOUNCE];
+        if (getenv("RT_BVH_DIAG") && h[ST_DIAG + 0] + h[ST_DIAG + 2] > 0)
+            std::fprintf(stderr, "[k_bvh<AO>] node steps %llu (%.1f lanes each), triangle steps %llu (%.1f lanes each), votes %llu (%.1f active lanes), refills %llu (%.1f rays each)\n",
+                         h[ST_DIAG], (double)h[ST_DIAG + 1] / std::max(1ull, h[ST_DIAG]), h[ST_DIAG + 2], (double)h[ST_DIAG + 3] / std::max(1ull, h[ST_DIAG + 2]),
+                         h[ST_DIAG + 4], (double)h[ST_DIAG + 5] / std::max(1ull, h[ST_DIAG + 4]), h[ST_DIAG + 6], (double)h[ST_DIAG + 7] / std::max(1ull, h[ST_DIAG + 6]));
         for (int k = 0; k < 3; ++k) { stats->nodes[k] = h[ST_NODES + k]; stats->tris[k] = h[ST_TRIS + k]; stats->gates[k] = h[ST_GATES + k]; stats->bvh_rays[k] = h[ST_BVHRAYS + k]; }
         float ms = 0.0f;
         HIPCHECK(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));

@@ -22,7 +22,9 @@ namespace rt {
 enum : uint8_t { LK_NONE = 0, LK_TERMINAL = 1, LK_MIRROR = 2, LK_REFRACT = 3 };
 // (C_AO is unused since AO work became positional: slot = path index)
 enum { C_QUEUE = 0, C_AO = 64, C_SH = 128, C_BQ = 192, C_BQA = 256, C_BQ_NEXT = 320, C_BQA_NEXT = 384, C_TOTAL = 448 };   // per-batch u32 counters, one per depth
-enum { ST_SHADOW = 0, ST_AO = 1, ST_BOUNCE = 2, ST_NODES = 3, ST_TRIS = 6, ST_GATES = 9, ST_BVHRAYS = 12, ST_TOTAL = 15 }; // u64
+enum { ST_SHADOW = 0, ST_AO = 1, ST_BOUNCE = 2, ST_NODES = 3, ST_TRIS = 6, ST_GATES = 9, ST_BVHRAYS = 12,
+       ST_DIAG = 15 /* k_bvh<AO> lane-packing diagnostics of the counting variant: node steps, lanes in them, triangle steps, lanes in them, votes, active lanes at votes, refills, lanes refilled */,
+       ST_TOTAL = 23 }; // u64
 #define RT_MAX_LEVELS 62
 
 struct Batch {
