@@ -125,3 +125,16 @@ def test_gate_classification_is_sound(emul):
         assert bad == 0, out
         assert no > 0.1 * tested and yes > 0.1 * tested   # both shortcuts are exercised
         assert amb < 0.35 * tested                        # the adversarial modes are ~3/8 of the cases
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_scenes(emul, port, seed):
+    """Fuzz (util.random_scene): the device code on the host must reproduce the oracle's primitive ids
+    and ray parameters exactly (conservative culling / gate shortcuts may never change a result)."""
+    w, params = util.random_scene(seed)
+    flat = w.flatten()
+    want = port.render(flat, w.camera, params, rng_mode=1, nthreads=4)
+    rgb, prim, t, cnt = emul.render(flat, w.camera, params)
+    assert np.array_equal(prim, want.primid)
+    assert util.bits_equal(t, want.t)
+    assert util.lsb_diff(rgb, want.rgb).max() <= 1

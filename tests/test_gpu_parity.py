@@ -271,3 +271,17 @@ def test_other_configs_properties_and_crop(gpu, port, which):
     same = prim[sl] == want.primid[sl]
     assert np.array_equal(t[sl][same].view(np.uint32), want.t[sl][same].view(np.uint32))
     assert util.lsb_diff(rgb[sl], want.rgb[sl]).max() <= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(16, 28)))
+def test_random_scenes(gpu, port, seed):
+    """The same fuzz scenes as tests/test_emul.py (other seeds) on the GPU."""
+    w, params = util.random_scene(seed)
+    flat = w.flatten()
+    want = port.render(flat, w.camera, params, rng_mode=1, nthreads=8)
+    gpu.upload(flat)
+    rgb, prim, t, st = gpu.render(w.camera, params, ids=True)
+    assert np.array_equal(prim, want.primid)
+    assert util.bits_equal(t, want.t)
+    assert util.lsb_diff(rgb, want.rgb).max() <= 1

@@ -110,3 +110,82 @@ def mesh_tunnel_scene(width=64, height=48, meshes=14):
     w.lights = [light]
     w.camera = S.Camera((2, 1, 160), (2, 1, -400), (0, 1, 0), 60.0 * height / 48.0)
     return w
+
+
+def random_scene(seed):
+    """Fuzz scene: a random mix of planes, spheres, free triangles, meshes and multi-meshes, some grouped
+    in BVHAccels of random size, random materials (all five classes) and lights, a camera aimed at one
+    of the meshes from inside or outside its box.  Returns (world, params)."""
+    import numpy as np
+    from raytracer_amd import scenes, scene as S
+    rng = np.random.default_rng(1000 + seed)
+    w = S.World()
+    w.width, w.height = 40, 30
+    w.sampler = S.Jitter(4, 7) if seed % 2 else S.Regular(1, 1)
+    tex = scenes.checker_texture()
+
+    def material():
+        k = int(rng.integers(0, 5))
+        if k == 0:
+            m = S.Matte(); m.setDiffuseColour(rng.random(3)); m.setDiffuseReflection(0.5 + rng.random()); m.setAmbientReflection(rng.random())
+        elif k == 1:
+            m = S.Specular(); m.setDiffuseColour(rng.random(3)); m.setAmbientReflection(rng.random())
+        elif k == 2:
+            m = S.Mirror(); m.setAmbientColour(rng.random(3)); m.setAmbientReflection(rng.random())
+        elif k == 3:
+            m = S.Refraction(); m.setIndexOfRefraction(1.0 + rng.random())
+        else:
+            m = S.Textured(tex); m.setAmbientReflection(rng.random())
+        return m
+
+    def opaque():   # planes and spheres cannot carry Textured (unsupported, stale uv in the reference)
+        while True:
+            m = material()
+            if not isinstance(m, S.Textured):
+                return m
+
+    shapes = []
+    for _ in range(int(rng.integers(1, 4))):
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        shapes.append(S.Plane(tuple(-n * rng.uniform(150, 400)), tuple(n)).setMaterial(opaque()))
+    for _ in range(int(rng.integers(1, 6))):
+        shapes.append(S.Sphere(tuple(rng.uniform(-200, 200, 3)), float(rng.uniform(10, 90))).setMaterial(opaque()))
+    for _ in range(int(rng.integers(0, 4))):
+        p = rng.uniform(-200, 200, (3, 3))
+        shapes.append(S.Triangle(tuple(p[0]), tuple(p[1]), tuple(p[2]), (0, 0), (1, 0), (0, 1)).setMaterial(material()))
+    mesh_at = []
+    for _ in range(int(rng.integers(1, 5))):
+        m = S.Textured(tex); m.setAmbientReflection(rng.random())
+        obj = scenes.torus_objmesh(m, int(rng.integers(3, 14)), int(rng.integers(3, 9)), R=float(rng.uniform(30, 110)), r=float(rng.uniform(8, 40)))
+        off = tuple(rng.uniform(-150, 150, 3))
+        mesh_at.append(off)
+        shapes.append(S.MultiMesh(obj, "", off) if rng.random() < 0.7 else S.Mesh(obj.shapes[0], off))
+    order = rng.permutation(len(shapes))
+    shapes = [shapes[i] for i in order]
+    scene = []
+    while shapes:
+        take = int(rng.integers(1, min(len(shapes), 7) + 1))
+        group, shapes = shapes[:take], shapes[take:]
+        if rng.random() < 0.6 and all(not isinstance(g, S.Plane) for g in group):
+            bvh = S.BVHAccel()
+            for g in group:
+                bvh.addShape(g)
+            bvh.generateBVH()
+            scene.append(bvh)
+        else:
+            scene += group
+    w.scene = scene
+    w.ambient = S.Ambient(int(rng.integers(0, 3)), float(rng.uniform(100, 1000)))
+    w.ambient.setColour((1, 1, 1)); w.ambient.scaleRadiance(0.5)
+    w.lights = []
+    for _ in range(int(rng.integers(0, 3))):
+        light = S.PointLight(tuple(rng.uniform(-500, 500, 3))) if rng.random() < 0.7 else S.Directional(tuple(rng.normal(size=3)))
+        light.setColour(tuple(rng.random(3))); light.scaleRadiance(float(rng.uniform(0.3, 1.5)))
+        w.lights.append(light)
+    look = np.array(mesh_at[int(rng.integers(0, len(mesh_at)))]) + np.array([0.0, 25.0, 0.0])   # torus_objmesh's own centre
+    away = rng.normal(size=3); away /= np.linalg.norm(away)
+    eye = look + away * rng.uniform(20, 420)   # sometimes inside the mesh's box
+    w.camera = S.Camera(tuple(eye), tuple(look + rng.uniform(-30, 30, 3)), (0, 1, 0), float(rng.uniform(15, 50)))
+    w.maxDepth = int(rng.integers(0, 5)) if hasattr(w, "maxDepth") else None
+    params = w.params(seed=seed)
+    return w, params
