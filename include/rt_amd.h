@@ -229,6 +229,15 @@ int rt_owned_tiles(const rt_params* p, int rank, int world, uint32_t* out);
 int rt_unpack_tiles(rt_ctx* ctx, const float* d_slab, const rt_params* p, int rank, int world,
                     float* d_frame, void* stream);
 
+/* Where rt_scene_commit builds the triangle BVHs of the Meshes (no reference counterpart:
+ * Mesh::hit scans all triangles, main.cpp:890-912).  RT_BUILDER_HOST_SAH (default): binned SAH on the host,
+ * multi-threaded — the better trees.  RT_BUILDER_GPU_LBVH: Morton-code radix trees built on the device — the
+ * faster build; falls back to the host builder when a tree would be deeper than the traversal stack.  A BVH
+ * only culls: both give bit-identical frames.  rt_scene_builder_used reports what the last commit used. */
+enum { RT_BUILDER_HOST_SAH = 0, RT_BUILDER_GPU_LBVH = 1 };
+int rt_scene_set_builder(rt_scene* scene, int builder);
+int rt_scene_builder_used(rt_scene* scene, int* builder, double* build_seconds);
+
 /* Resolve step of saveToFile (main.cpp:1842-1850): uchar(pixel*255), truncating, on device. */
 int rt_quantize_rgb8(rt_ctx* ctx, const float* d_rgb, size_t num_pixels, uint8_t* d_rgb8, void* stream);
 

@@ -106,6 +106,8 @@ def default_params(width=1000, height=1000, num_samples=4, num_sets=83, sampler=
 
 
 # ---- the HIP library ------------------------------------------------------------------------
+RT_BUILDER_HOST_SAH, RT_BUILDER_GPU_LBVH = 0, 1
+
 _EXPORTS = [
     "rt_init", "rt_shutdown", "rt_last_error", "rt_version", "rt_params_default",
     "rt_scene_create", "rt_scene_set_planes", "rt_scene_set_spheres", "rt_scene_set_triangles",
@@ -113,7 +115,7 @@ _EXPORTS = [
     "rt_scene_set_materials", "rt_scene_set_textures", "rt_scene_set_lights", "rt_scene_set_ambient",
     "rt_scene_set_desc", "rt_scene_commit", "rt_scene_destroy",
     "rt_render", "rt_render_device", "rt_owned_tiles", "rt_unpack_tiles", "rt_quantize_rgb8",
-    "rt_bmp24_bytes", "rt_encode_bmp24",
+    "rt_bmp24_bytes", "rt_encode_bmp24", "rt_scene_set_builder", "rt_scene_builder_used",
 ]
 
 _lib = None
@@ -157,6 +159,8 @@ def load_library(path=None):
     lib.rt_owned_tiles.argtypes = [C.POINTER(rt_params), C.c_int, C.c_int, C.POINTER(C.c_uint32)]
     lib.rt_unpack_tiles.argtypes = [vp, vp, C.POINTER(rt_params), C.c_int, C.c_int, vp, vp]
     lib.rt_quantize_rgb8.argtypes = [vp, vp, C.c_size_t, vp, vp]
+    lib.rt_scene_set_builder.argtypes = [vp, C.c_int]
+    lib.rt_scene_builder_used.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     lib.rt_bmp24_bytes.argtypes = [C.c_int, C.c_int]
     lib.rt_bmp24_bytes.restype = C.c_size_t
     lib.rt_encode_bmp24.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]

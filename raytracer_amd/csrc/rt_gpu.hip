@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -18,6 +19,7 @@
 #include <vector>
 
 #include "rt_pipeline.hpp"
+#include "rt_lbvh.hpp"
 #include "rt_scene.hpp"
 
 using namespace rt;
@@ -411,6 +413,9 @@ struct rt_scene {
     bool committed = false;
     DScene dev{};
     std::vector<void*> allocs;
+    int builder = RT_BUILDER_HOST_SAH;        // requested (rt_scene_set_builder)
+    int builder_used = RT_BUILDER_HOST_SAH;   // what the last commit built the triangle BVHs with
+    double build_seconds = 0.0;               // triangle BVHs of the last commit (host: all of HostScene::build)
 };
 
 static std::string g_init_error;
@@ -693,11 +698,35 @@ int rt_scene_commit(rt_scene* s)
     rt_ctx* ctx = s->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHECK(ctx, hipSetDevice(ctx->device));
-    int rc = s->host.build();
-    if (rc) { ctx->error = "rt_scene_commit: " + s->host.error; return rc; }
+    HostScene& H = s->host;
+    const auto t_build = std::chrono::steady_clock::now();
+    H.gpu_bvh = s->builder == RT_BUILDER_GPU_LBVH;
+    int rc = H.build();
+    if (rc) { ctx->error = "rt_scene_commit: " + H.error; return rc; }
     HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
     scene_free_device(s);
-    HostScene& H = s->host;
+    q4 *lb_tris = nullptr, *lb_nodes = nullptr;
+    s->builder_used = RT_BUILDER_HOST_SAH;
+    if (H.gpu_bvh) {
+        uint32_t depth = 0;
+        double secs = 0.0;
+        std::string err;
+        rc = lbvh_build(H, ctx->stream, &lb_tris, &lb_nodes, &depth, &secs, err);
+        if (rc) { ctx->error = "rt_scene_commit: " + err; return rc; }
+        if (depth > 25u) {   // deeper than the traversal stacks allow (rt_scene.cpp kMaxDepth + 1): the host builder bounds its depth
+            (void)hipFree(lb_tris); (void)hipFree(lb_nodes);
+            lb_tris = lb_nodes = nullptr;
+            H.gpu_bvh = false;
+            rc = H.build();
+            if (rc) { ctx->error = "rt_scene_commit: " + H.error; return rc; }
+        } else {
+            s->allocs.push_back(lb_tris); s->allocs.push_back(lb_nodes);
+            s->builder_used = RT_BUILDER_GPU_LBVH;
+            s->build_seconds = secs;
+            H.bvh_max_depth = depth;
+        }
+    }
+    if (s->builder_used == RT_BUILDER_HOST_SAH) s->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count();
     auto up = [&](const void* src, size_t bytes, const void** dst) -> int {
         void* d = nullptr;
         size_t b = bytes ? bytes : 16;
@@ -711,9 +740,12 @@ int rt_scene_commit(rt_scene* s)
     if ((rc = up(H.gates.data(), H.gates.size() * sizeof(GateNode), (const void**)&D.gates))) return rc;
     if ((rc = up(H.planes4.data(), H.planes4.size() * sizeof(q4), (const void**)&D.planes))) return rc;
     if ((rc = up(H.spheres4.data(), H.spheres4.size() * sizeof(q4), (const void**)&D.spheres))) return rc;
-    if ((rc = up(H.tris4.data(), H.tris4.size() * sizeof(q4), (const void**)&D.tris))) return rc;
+    if (lb_tris) { D.tris = lb_tris; D.nodes = lb_nodes; }
+    else {
+        if ((rc = up(H.tris4.data(), H.tris4.size() * sizeof(q4), (const void**)&D.tris))) return rc;
+        if ((rc = up(H.nodes4.data(), H.nodes4.size() * sizeof(q4), (const void**)&D.nodes))) return rc;
+    }
     if ((rc = up(H.attr4.data(), H.attr4.size() * sizeof(q4), (const void**)&D.tri_attr))) return rc;
-    if ((rc = up(H.nodes4.data(), H.nodes4.size() * sizeof(q4), (const void**)&D.nodes))) return rc;
     if ((rc = up(H.dmaterials.data(), H.dmaterials.size() * sizeof(DMaterial), (const void**)&D.materials))) return rc;
     if ((rc = up(H.dlights.data(), H.dlights.size() * sizeof(DLight), (const void**)&D.lights))) return rc;
     if ((rc = up(H.dtextures.data(), H.dtextures.size() * sizeof(DTexture), (const void**)&D.textures))) return rc;
@@ -733,6 +765,24 @@ int rt_scene_commit(rt_scene* s)
     H.fill_lead_planes(D);
     D.debug = getenv("RT_DEBUG") ? (uint32_t)atoi(getenv("RT_DEBUG")) : 0u;
     s->committed = true;
+    return RT_OK;
+}
+
+int rt_scene_set_builder(rt_scene* s, int builder)
+{
+    if (!s) return RT_ERR_INVALID;
+    if (builder != RT_BUILDER_HOST_SAH && builder != RT_BUILDER_GPU_LBVH) { s->ctx->error = "rt_scene_set_builder: unknown builder"; return RT_ERR_INVALID; }
+    s->builder = builder;
+    s->committed = false;
+    return RT_OK;
+}
+
+int rt_scene_builder_used(rt_scene* s, int* builder, double* build_seconds)
+{
+    if (!s) return RT_ERR_INVALID;
+    if (!s->committed) { s->ctx->error = "rt_scene_builder_used: scene not committed"; return RT_ERR_INVALID; }
+    if (builder) *builder = s->builder_used;
+    if (build_seconds) *build_seconds = s->build_seconds;
     return RT_OK;
 }
 

@@ -1,0 +1,17 @@
+// rt_lbvh.hpp — device-side triangle-BVH builder (rt_lbvh.hip), called by rt_scene_commit when the scene's
+// builder is RT_BUILDER_GPU_LBVH.  H must have been built with gpu_bvh set (slot / node layout only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "rt_amd.h"
+#include "rt_core.hpp"
+#include "rt_scene.hpp"
+
+namespace rt {
+// On RT_OK: *d_tris (3 q4 per slot) and *d_nodes (2 q4 per node) are device allocations owned by the caller,
+// *max_depth = inner nodes on the longest root-to-leaf path (the caller compares it with the stack bound),
+// *seconds = wall time of the build including the triangle upload.
+int lbvh_build(const HostScene& H, hipStream_t stream, q4** d_tris, q4** d_nodes, uint32_t* max_depth, double* seconds, std::string& err);
+}

@@ -234,6 +234,11 @@ void HostScene::write_triangle_slot(uint32_t slot, uint32_t gid, uint32_t rank)
 
 uint32_t HostScene::add_triangle_slot(uint32_t gid, uint32_t rank)
 {
+    if (gpu_bvh) {   // a free triangle: one slot, no node
+        Occurrence o{gid, 1u, rank, gpu_slots, 0xFFFFFFFFu, {0, 0, 0}, {0, 0, 0}};
+        occurrences.push_back(o);
+        return gpu_slots++;
+    }
     uint32_t slot = (uint32_t)(tris4.size() / 3);
     tris4.resize(tris4.size() + 3);
     write_triangle_slot(slot, gid, rank);
@@ -446,6 +451,15 @@ uint32_t HostScene::mesh_bvh(uint32_t mesh, uint32_t rank_base)
     // triangle records carry their absolute rank, so a Mesh reachable through two gate nodes gets two BVH copies
     if (mesh_root_[mesh] != 0xFFFFFFFFu && mesh_rank_[mesh] == rank_base) return mesh_root_[mesh];
     const rt_mesh& m = meshes[mesh];
+    if (gpu_bvh) {
+        Occurrence o{m.first_triangle, m.num_triangles, rank_base, gpu_slots, gpu_nodes, {0, 0, 0}, {0, 0, 0}};
+        std::memcpy(o.mn, mesh_box_[mesh].mn, 12); std::memcpy(o.mx, mesh_box_[mesh].mx, 12);
+        occurrences.push_back(o);
+        gpu_slots += m.num_triangles;
+        gpu_nodes += std::max(1u, m.num_triangles - 1u);   // a radix tree over n keys has n - 1 inner nodes; <= 2 triangles: one root node
+        mesh_root_[mesh] = o.node_off; mesh_rank_[mesh] = rank_base;
+        return o.node_off;
+    }
     const BvhPart& part = mesh_part_[mesh];
     // reserve this occurrence's node and slot ranges now (the layout is that of a sequential build); the
     // copies themselves run on all threads after the emission pass (run_append_jobs)
@@ -676,7 +690,8 @@ int HostScene::build()
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     const auto t_begin = now();
-    prebuild_mesh_parts();
+    occurrences.clear(); gpu_slots = gpu_nodes = 0;
+    if (!gpu_bvh) prebuild_mesh_parts(); else { mesh_part_.clear(); }
     const auto t_parts = now();
     mesh_rank_.assign(meshes.size(), 0);
 
@@ -746,6 +761,19 @@ int HostScene::build()
     const auto t_walk = now();
     run_append_jobs();
     const auto t_emit = now();
+    if (gpu_bvh) {   // the node grid of quantize_nodes(), from the boxes the nodes will lie in
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (auto& o : occurrences) {
+            if (o.node_off == 0xFFFFFFFFu) continue;
+            for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], o.mn[a]); mx[a] = std::max(mx[a], o.mx[a]); }
+        }
+        for (int a = 0; a < 3; ++a) {
+            if (!(mn[a] <= mx[a])) { mn[a] = 0.0f; mx[a] = 1.0f; }
+            qbase[a] = mn[a];
+            qscale[a] = std::max((mx[a] - mn[a]) / 65533.0f, 1e-30f);
+        }
+        if ((uint64_t)gpu_slots >= (1ull << 28)) { error = "too many triangle slots for a leaf reference"; return RT_ERR_UNSUPPORTED; }
+    } else
     quantize_nodes();
     mesh_part_.clear(); mesh_part_.shrink_to_fit();
     if (timing) std::fprintf(stderr, "[rt_scene] reference hierarchies alone %.3f s\n", hierarchy_seconds_);

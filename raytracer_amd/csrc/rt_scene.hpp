@@ -48,6 +48,14 @@ struct HostScene {
     std::string error;
 
     int build();   // rt_status
+
+    // with gpu_bvh set, build() does everything but the triangle BVHs: it lays out the slot and
+    // node ranges of every Mesh occurrence (and of the free triangles) and leaves tris4 / nodes4 empty; the LBVH
+    // builder on the device (rt_lbvh.hip) fills them.  Node 0 of an occurrence's range is its root.
+    struct Occurrence { uint32_t first_triangle, count, rank_base, slot_off, node_off; float mn[3], mx[3]; };
+    bool gpu_bvh = false;
+    std::vector<Occurrence> occurrences;   // gpu_bvh only
+    uint32_t gpu_slots = 0, gpu_nodes = 0; // totals of the layout (gpu_bvh only)
     // One (sub)tree built into its own buffers, with node indices and triangle slots local to them, so that
     // independent subtrees and meshes can be built on different threads and appended afterwards.
     struct BvhPart {

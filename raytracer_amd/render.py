@@ -31,8 +31,9 @@ class Renderer:
             raise RtError(f"{what} failed ({rc}): {self.lib.rt_last_error(self.ctx).decode()}")
 
     # -- scene -------------------------------------------------------------------------------
-    def upload(self, world_or_flat):
-        """rt_scene_create + rt_scene_set_* + rt_scene_commit."""
+    def upload(self, world_or_flat, builder=None):
+        """rt_scene_create + rt_scene_set_* + rt_scene_commit.  builder: capi.RT_BUILDER_HOST_SAH (default) or
+        capi.RT_BUILDER_GPU_LBVH (triangle BVHs built on the device; see builder_used())."""
         flat = world_or_flat.flatten() if hasattr(world_or_flat, "flatten") else world_or_flat
         if self.scene is not None:
             self.lib.rt_scene_destroy(self.scene)
@@ -56,9 +57,17 @@ class Renderer:
         self._check(L.rt_scene_set_textures(sc, d.textures, d.num_textures), "rt_scene_set_textures")
         self._check(L.rt_scene_set_lights(sc, ptr(A["lights"]), len(A["lights"])), "rt_scene_set_lights")
         self._check(L.rt_scene_set_ambient(sc, C.byref(d.ambient)), "rt_scene_set_ambient")
+        if builder is not None:
+            self._check(L.rt_scene_set_builder(sc, int(builder)), "rt_scene_set_builder")
         self._check(L.rt_scene_commit(sc), "rt_scene_commit")
         self._flat = flat
         return self
+
+    def builder_used(self):
+        """(builder, seconds) of the last commit's triangle-BVH build."""
+        b, t = C.c_int(), C.c_double()
+        self._check(self.lib.rt_scene_builder_used(self.scene, C.byref(b), C.byref(t)), "rt_scene_builder_used")
+        return b.value, t.value
 
     # -- render ------------------------------------------------------------------------------
     def render(self, camera, params, ids=False, stats=True, rgb=None):

@@ -285,3 +285,57 @@ def test_random_scenes(gpu, port, seed):
     assert np.array_equal(prim, want.primid)
     assert util.bits_equal(t, want.t)
     assert util.lsb_diff(rgb, want.rgb).max() <= 1
+
+
+@pytest.mark.gpu
+def test_gpu_built_bvh_renders_the_same_frame(gpu):
+    """triangle BVHs built on the device (LBVH) instead of the host (binned SAH).  A BVH only
+    culls, so the frames must agree bit for bit; fuzz scenes, the mesh tunnel, 400 instanced meshes."""
+    from raytracer_amd import scenes
+    cases = [util.random_scene(s) for s in (3, 4, 6, 7, 10, 11)]
+    w = util.mesh_tunnel_scene(96, 72); cases.append((w, w.params(seed=5)))
+    w = scenes.config5_scene(320, 180, 4, instances=400); cases.append((w, w.params(seed=2)))
+    w = scenes.config3_scene(256, 144, 4, mesh_nu=120, mesh_nv=60); cases.append((w, w.params(seed=2)))
+    for w, params in cases:
+        flat = w.flatten()
+        gpu.upload(flat)
+        assert gpu.builder_used()[0] == capi.RT_BUILDER_HOST_SAH
+        want, wid, wt, wst = gpu.render(w.camera, params, ids=True)
+        gpu.upload(flat, builder=capi.RT_BUILDER_GPU_LBVH)
+        assert gpu.builder_used()[0] == capi.RT_BUILDER_GPU_LBVH
+        got, gid, gt, gst = gpu.render(w.camera, params, ids=True)
+        assert np.array_equal(gid, wid) and util.bits_equal(gt, wt) and util.bits_equal(got, want)
+        assert gst.rays == wst.rays
+    gpu.upload(cases[0][0].flatten())
+
+
+@pytest.mark.gpu
+def test_gpu_builder_falls_back_when_the_tree_is_too_deep(gpu):
+    """Triangles at exponentially spaced positions give a radix tree deeper than the traversal stack: the commit
+    must fall back to the depth-bounded host builder (and render the same frame as a host-built scene)."""
+    from raytracer_amd import scene as S, scenes
+    w = S.World(); w.width, w.height = 48, 32; w.sampler = S.Regular(1, 1)
+    tex = S.Textured(scenes.checker_texture())
+    # Morton codes with a single bit set (cells (2^j,0,0), (0,2^j,0), (0,0,2^j) of the mesh box's 1024^3 grid) plus
+    # the two box corners: every key bit splits one triangle off, a chain of ~29 inner nodes
+    cells = [(0, 0, 0), (1023, 1023, 1023)]
+    for j in range(10):
+        cells += [(2 ** j, 0, 0), (0, 2 ** j, 0), (0, 0, 2 ** j)]
+    P = []
+    for c in cells:
+        x, y, z = (v + 0.5 for v in c)
+        P += [(x - 0.2, y - 0.2, z), (x + 0.2, y - 0.2, z), (x, y + 0.2, z)]
+    n = len(cells)
+    uv = np.tile(np.array([(0.0, 0.0), (0.9, 0.0), (0.0, 0.9)]), (n, 1))
+    obj = S.ObjMesh([S.ObjShape(np.array(P), uv, np.arange(3 * n).reshape(n, 3), tex)])
+    w.scene = [S.MultiMesh(obj, "", (0, 0, 0))]
+    w.ambient = S.Ambient(0); w.lights = []
+    w.camera = S.Camera((8, 8, 60), (8, 8, 0), (0, 1, 0), 40.0)
+    flat = w.flatten()
+    gpu.upload(flat)
+    want, wid, _, _ = gpu.render(w.camera, w.params(), ids=True)
+    assert (wid != capi.RT_MISS).any()
+    gpu.upload(flat, builder=capi.RT_BUILDER_GPU_LBVH)
+    assert gpu.builder_used()[0] == capi.RT_BUILDER_HOST_SAH
+    got, gid, _, _ = gpu.render(w.camera, w.params(), ids=True)
+    assert np.array_equal(gid, wid) and util.bits_equal(got, want)

@@ -4,4 +4,4 @@
 set -e
 cd "$(dirname "$0")/../raytracer_amd/csrc"
 mkdir -p ../../tune
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -I../../include -I. -w $2 -shared rt_gpu.hip rt_scene.cpp -o ../../tune/$1.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -I../../include -I. -w $2 -shared rt_gpu.hip rt_lbvh.hip rt_scene.cpp -o ../../tune/$1.so
