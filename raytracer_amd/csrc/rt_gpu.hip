@@ -711,9 +711,11 @@ int rt_scene_commit(rt_scene* s)
         uint32_t depth = 0;
         double secs = 0.0;
         std::string err;
-        rc = lbvh_build(H, ctx->stream, &lb_tris, &lb_nodes, &depth, &secs, err);
+        // inner levels the traversal stacks allow (rt_scene.cpp kMaxDepth + 1); RT_LBVH_MAX_DEPTH lowers it to test the fallback
+        const uint32_t max_ok = getenv("RT_LBVH_MAX_DEPTH") ? (uint32_t)atoi(getenv("RT_LBVH_MAX_DEPTH")) : 25u;
+        rc = lbvh_build(H, ctx->stream, max_ok, &lb_tris, &lb_nodes, &depth, &secs, err);
         if (rc) { ctx->error = "rt_scene_commit: " + err; return rc; }
-        if (depth > 25u) {   // deeper than the traversal stacks allow (rt_scene.cpp kMaxDepth + 1): the host builder bounds its depth
+        if (depth > max_ok) {   // deeper than the traversal stacks allow (rt_scene.cpp kMaxDepth + 1): the host builder bounds its depth
             (void)hipFree(lb_tris); (void)hipFree(lb_nodes);
             lb_tris = lb_nodes = nullptr;
             H.gpu_bvh = false;

@@ -98,7 +98,9 @@ struct Tree {
 };
 
 // Karras 2012: the node's key range and split from common-prefix lengths; equal keys are told apart by index
-__global__ void __launch_bounds__(LB_BLOCK) k_tree(const DOcc* mocc, uint32_t nmocc, const unsigned long long* keys, uint32_t nnodes, Tree T)
+// `shift` ignores that many low Morton bits: fewer radix levels; the triangles of one (coarser) cell are then split
+// by index, which is balanced and, the keys being sorted by the full code, still follows the Morton curve.
+__global__ void __launch_bounds__(LB_BLOCK) k_tree(const DOcc* mocc, uint32_t nmocc, const unsigned long long* keys, uint32_t nnodes, uint32_t shift, Tree T)
 {
     const uint32_t g = blockIdx.x * LB_BLOCK + threadIdx.x;
     if (g >= nnodes) return;
@@ -108,10 +110,10 @@ __global__ void __launch_bounds__(LB_BLOCK) k_tree(const DOcc* mocc, uint32_t nm
     if (i == 0) T.parent_node[g] = 0x7FFFFFFFu;
     if (n <= 2) return;   // one root node over a single leaf: written by k_nodes
     const unsigned long long* K = keys + o.slot_off;
-    const unsigned long long ki = K[i];
+    const unsigned long long ki = K[i] >> shift;
     auto delta = [&](int b) -> int {
         if (b < 0 || b >= n) return -1;
-        const unsigned long long kb = K[b];
+        const unsigned long long kb = K[b] >> shift;
         return ki == kb ? 64 + __clz((uint32_t)(i ^ b)) : __clzll((long long)(ki ^ kb));
     };
     const int d = delta(i + 1) > delta(i - 1) ? 1 : -1;
@@ -268,7 +270,7 @@ struct Scratch {
         if (e_ != hipSuccess) { err = std::string("lbvh_build: ") + #call + ": " + hipGetErrorString(e_); return RT_ERR_HIP; } \
     } while (0)
 
-int lbvh_build(const HostScene& H, hipStream_t stream, q4** d_tris, q4** d_nodes, uint32_t* max_depth, double* seconds, std::string& err)
+int lbvh_build(const HostScene& H, hipStream_t stream, uint32_t max_ok, q4** d_tris, q4** d_nodes, uint32_t* max_depth, double* seconds, std::string& err)
 {
     const auto t0 = std::chrono::steady_clock::now();
     const uint32_t nslots = H.gpu_slots, nnodes = H.gpu_nodes;
@@ -304,25 +306,35 @@ int lbvh_build(const HostScene& H, hipStream_t stream, q4** d_tris, q4** d_nodes
         return fail(std::string("lbvh_build: upload: ") + hipGetErrorString(e));
 
     const uint32_t gs = (nslots + LB_BLOCK - 1) / LB_BLOCK, gn = (nnodes + LB_BLOCK - 1) / LB_BLOCK;
-    hipLaunchKernelGGL(k_keys, dim3(gs), dim3(LB_BLOCK), 0, stream, d_tri, d_all, (uint32_t)all.size(), nslots, k0, v0);
     size_t tmp_bytes = 0;
     if ((e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, v0, v1, (size_t)nslots, 0u, 64u, stream)) != hipSuccess)
         return fail(std::string("lbvh_build: radix sort (size query): ") + hipGetErrorString(e));
     char* tmp = nullptr;
     if ((e = S.get(&tmp, tmp_bytes)) != hipSuccess) return fail(std::string("lbvh_build: hipMalloc: ") + hipGetErrorString(e));
+    // A radix tree is as deep as its keys are long (plus the index levels of equal keys); the traversal stack
+    // allows max_ok inner levels.  Retry with shorter Morton codes before giving up (the caller then falls
+    // back to the host builder).
+    hipLaunchKernelGGL(k_keys, dim3(gs), dim3(LB_BLOCK), 0, stream, d_tri, d_all, (uint32_t)all.size(), nslots, k0, v0);
     if ((e = rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, v0, v1, (size_t)nslots, 0u, 64u, stream)) != hipSuccess)
         return fail(std::string("lbvh_build: radix sort: ") + hipGetErrorString(e));
+    static const uint32_t shifts[] = {0, 3, 6, 9, 12, 15};
+    for (uint32_t attempt = 0; nnodes && attempt < sizeof shifts / sizeof shifts[0]; ++attempt) {
+        if ((e = hipMemsetAsync(d_depth, 0, 4, stream)) != hipSuccess) return fail(std::string("lbvh_build: ") + hipGetErrorString(e));
+        hipLaunchKernelGGL(k_tree, dim3(gn), dim3(LB_BLOCK), 0, stream, d_mesh, (uint32_t)mesh.size(), k1, nnodes, shifts[attempt], T);
+        hipLaunchKernelGGL(k_depth, dim3(gs), dim3(LB_BLOCK), 0, stream, d_all, (uint32_t)all.size(), nslots, T, d_depth);
+        if ((e = hipGetLastError()) != hipSuccess) return fail(std::string("lbvh_build: launch: ") + hipGetErrorString(e));
+        if ((e = hipMemcpyAsync(max_depth, d_depth, 4, hipMemcpyDeviceToHost, stream)) || (e = hipStreamSynchronize(stream)))
+            return fail(std::string("lbvh_build: ") + hipGetErrorString(e));
+        if (*max_depth <= max_ok) break;
+    }
     hipLaunchKernelGGL(k_records, dim3(gs), dim3(LB_BLOCK), 0, stream, d_tri, d_all, k1, v1, nslots, tris);
     if (nnodes) {
-        hipLaunchKernelGGL(k_tree, dim3(gn), dim3(LB_BLOCK), 0, stream, d_mesh, (uint32_t)mesh.size(), k1, nnodes, T);
         hipLaunchKernelGGL(k_fit, dim3(gs), dim3(LB_BLOCK), 0, stream, d_tri, d_all, (uint32_t)all.size(), v1, nslots, T);
-        hipLaunchKernelGGL(k_depth, dim3(gs), dim3(LB_BLOCK), 0, stream, d_all, (uint32_t)all.size(), nslots, T, d_depth);
         hipLaunchKernelGGL(k_nodes, dim3(gn), dim3(LB_BLOCK), 0, stream, d_mesh, (uint32_t)mesh.size(), nnodes, T,
                            F3(H.qbase[0], H.qbase[1], H.qbase[2]), F3(H.qscale[0], H.qscale[1], H.qscale[2]), nodes);
     }
     if ((e = hipGetLastError()) != hipSuccess) return fail(std::string("lbvh_build: launch: ") + hipGetErrorString(e));
-    if ((e = hipMemcpyAsync(max_depth, d_depth, 4, hipMemcpyDeviceToHost, stream)) || (e = hipStreamSynchronize(stream)))
-        return fail(std::string("lbvh_build: ") + hipGetErrorString(e));
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail(std::string("lbvh_build: ") + hipGetErrorString(e));
     *d_tris = tris; *d_nodes = nodes;
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return RT_OK;

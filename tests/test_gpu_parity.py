@@ -310,9 +310,12 @@ def test_gpu_built_bvh_renders_the_same_frame(gpu):
 
 
 @pytest.mark.gpu
-def test_gpu_builder_falls_back_when_the_tree_is_too_deep(gpu):
-    """Triangles at exponentially spaced positions give a radix tree deeper than the traversal stack: the commit
-    must fall back to the depth-bounded host builder (and render the same frame as a host-built scene)."""
+def test_gpu_builder_depth_bound_and_fallback(gpu):
+    """Triangles whose Morton codes have a single bit set give a radix tree (~29 levels) deeper than the traversal
+    stack allows (25): the device builder must shorten its codes until the tree fits; with the bound forced
+    to 3 levels (RT_LBVH_MAX_DEPTH) nothing fits and the commit falls back to the host builder.  Same frame
+    every time."""
+    import os
     from raytracer_amd import scene as S, scenes
     w = S.World(); w.width, w.height = 48, 32; w.sampler = S.Regular(1, 1)
     tex = S.Textured(scenes.checker_texture())
@@ -336,6 +339,14 @@ def test_gpu_builder_falls_back_when_the_tree_is_too_deep(gpu):
     want, wid, _, _ = gpu.render(w.camera, w.params(), ids=True)
     assert (wid != capi.RT_MISS).any()
     gpu.upload(flat, builder=capi.RT_BUILDER_GPU_LBVH)
+    assert gpu.builder_used()[0] == capi.RT_BUILDER_GPU_LBVH
+    got, gid, _, _ = gpu.render(w.camera, w.params(), ids=True)
+    assert np.array_equal(gid, wid) and util.bits_equal(got, want)
+    os.environ["RT_LBVH_MAX_DEPTH"] = "3"
+    try:
+        gpu.upload(flat, builder=capi.RT_BUILDER_GPU_LBVH)
+    finally:
+        del os.environ["RT_LBVH_MAX_DEPTH"]
     assert gpu.builder_used()[0] == capi.RT_BUILDER_HOST_SAH
     got, gid, _, _ = gpu.render(w.camera, w.params(), ids=True)
     assert np.array_equal(gid, wid) and util.bits_equal(got, want)
