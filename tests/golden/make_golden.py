@@ -11,6 +11,13 @@ sample points drawn from it (see oracle/ref_harness.cpp), which makes jitter + A
 Also writes known-answer vectors of single reference functions (kat.npz) and the reference's own
 decode of models/teapot/default.png (teapot_default_rgba.npz).
 Usage:  python tests/golden/make_golden.py        (needs /root/reference; run in the build container)
+        python tests/golden/make_golden.py converged    only the stochastic fixture below (about 4 minutes)
+
+converged_default_libc_rand.npz (SURVEY.md 8c "stochastic parity protocol"): the mean of 32 independent
+runs of the unmodified reference (rng_mode 0: libc rand() and its own Sampler with std::random_device,
+8 pool threads) on the default scene at 72x72, Jitter(16,83), 4x4 ambient occlusion = 512 samples per
+pixel, plus the leave-one-out PSNR of the single runs against the mean of the others.  The file changes
+from run to run by design; the tests that read it only use statistics with wide margins.
 """
 import ctypes as C
 import os
@@ -28,8 +35,25 @@ from oracle.bindings import RefOracle, f3  # noqa: E402
 from raytracer_amd import capi  # noqa: E402
 
 
+def converged(ref, runs=32):
+    from raytracer_amd import scenes, scene as S
+    w = scenes.default_scene(72, 72, sampler=S.Jitter(16, 83), ao_samples=4)
+    flat, p = w.flatten(), w.params()
+    imgs = np.stack([ref.render(flat, w.camera, p, rng_mode=0, nthreads=8, ids=False).rgb.astype(np.float64)
+                     for _ in range(runs)])
+    total = imgs.sum(axis=0)
+    loo = [util.psnr(imgs[k], (total - imgs[k]) / (runs - 1)) for k in range(runs)]
+    np.savez_compressed(os.path.join(HERE, "converged_default_libc_rand.npz"), rgb=(total / runs).astype(np.float32),
+                        runs=np.int32(runs), single_run_psnr=np.array(loo, np.float64),
+                        params=np.frombuffer(bytes(p), dtype=np.uint8))
+    print("converged: single-run PSNR against the mean of the others %.2f dB (min %.2f)" % (np.mean(loo), np.min(loo)))
+
+
 def main():
     ref = RefOracle()
+    if sys.argv[1:] == ["converged"]:
+        converged(ref)
+        return
     for name, world, params in util.small_scenes():
         flat = world.flatten()
         r = ref.render(flat, world.camera, params, rng_mode=1, nthreads=8)

@@ -350,3 +350,31 @@ def test_gpu_builder_depth_bound_and_fallback(gpu):
     assert gpu.builder_used()[0] == capi.RT_BUILDER_HOST_SAH
     got, gid, _, _ = gpu.render(w.camera, w.params(), ids=True)
     assert np.array_equal(gid, wid) and util.bits_equal(got, want)
+
+
+def test_converges_to_the_unmodified_reference(gpu):
+    """SURVEY.md 8c stochastic protocol against tests/golden/converged_default_libc_rand.npz: the mean of 32
+    runs of the UNMODIFIED reference (libc rand(), its own Sampler).  (ii) one GPU frame at 16 spp is as close
+    to that mean as one reference frame is (within 0.5 dB); (iii) the mean of 32 GPU frames with different
+    seeds agrees with it to >= 45 dB, the north star's bar, which here tests for bias (a different generator
+    draws different samples, so a single frame can only meet the reference's own noise floor of ~43 dB)."""
+    import os
+    from raytracer_amd import scenes, scene as S
+    g = np.load(os.path.join(util.GOLDEN, "converged_default_libc_rand.npz"))
+    w = scenes.default_scene(72, 72, sampler=S.Jitter(16, 83), ao_samples=4)
+    p = w.params()
+    assert bytes(p) == g["params"].tobytes()
+    gpu.upload(w)
+    runs = int(g["runs"])
+    acc = np.zeros((72, 72, 3), np.float64)
+    single = []
+    for seed in range(1, runs + 1):
+        p.seed = seed
+        rgb, _, _, _ = gpu.render(w.camera, p)
+        single.append(util.psnr(rgb, g["rgb"]))
+        acc += rgb
+    ref_single = float(np.mean(g["single_run_psnr"]))
+    print(f"single frame vs converged reference: GPU {np.mean(single):.2f} dB, reference {ref_single:.2f} dB; "
+          f"converged vs converged {util.psnr(acc / runs, g['rgb']):.2f} dB")
+    assert np.mean(single) >= ref_single - 0.5
+    assert util.psnr(acc / runs, g["rgb"]) >= 45.0
