@@ -698,6 +698,7 @@ int rt_scene_commit(rt_scene* s)
     rt_ctx* ctx = s->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHECK(ctx, hipSetDevice(ctx->device));
+    s->committed = false;   // a commit that fails half-way leaves no renderable scene behind
     HostScene& H = s->host;
     const auto t_build = std::chrono::steady_clock::now();
     H.gpu_bvh = s->builder == RT_BUILDER_GPU_LBVH;

@@ -92,6 +92,8 @@ def test_errors_are_reported(gpu):
     w.scene.append(bad)
     with pytest.raises(RtError):
         gpu.upload(w)
+    with pytest.raises(RtError, match="not committed"):   # a failed commit leaves nothing to render
+        gpu.render(w.camera, w.params())
     w = scenes.default_scene(32, 32)
     gpu.upload(w)
     p = w.params()
