@@ -136,7 +136,7 @@ RT_FN bool plane_t(f3 point, f3 normal, f3 o, f3 d, float& t)
 // (<= 2.4e-7 * (|o| + extent) per coordinate), so a slab test over t >= 0 on the box grown by
 // pad = cull_pad * (|o|_inf + extent) (16x that bound) that MISSES proves the exact test fails.
 // A pre-test that passes decides nothing: box_intersects still runs.  1/d may be approximate.
-struct RayGate { float ix, iy, iz, pad; };
+struct RayGate { float ix, iy, iz, pad, lx, ly, lz, hx, hy, hz; };
 
 RT_FN float approx_rcp(float x)
 {
@@ -147,6 +147,11 @@ RT_FN float approx_rcp(float x)
 #endif
 }
 
+// The slab distances are affine in the box coordinate c: (c -+ pad - o) / d = c * (1/d) + (-o -+ pad)/d, so the
+// pre-test is 6 fma + min/max (cf. make_cull / cull_box below).  Folded into the per-ray constants: the space
+// margin pad, and E = 2^-18 * (extent*|1/d| + |l| + |h|) per axis, a bound (16x the true one) on the rounding of
+// c*(1/d) + l itself for |c| <= extent — approximate reciprocal, two products, one fma — which moves each axis'
+// entry distance earlier and its exit distance later.
 RT_FN RayGate make_gate(float cull_pad, float extent, f3 o, f3 d)
 {
     RayGate r;
@@ -155,18 +160,28 @@ RT_FN RayGate make_gate(float cull_pad, float extent, f3 o, f3 d)
     float dy = fabsf(d.y) > 1e-20f ? d.y : (d.y < 0 ? -1e-20f : 1e-20f);
     float dz = fabsf(d.z) > 1e-20f ? d.z : (d.z < 0 ? -1e-20f : 1e-20f);
     r.ix = approx_rcp(dx); r.iy = approx_rcp(dy); r.iz = approx_rcp(dz);
+    r.lx = (-o.x - r.pad) * r.ix; r.hx = (-o.x + r.pad) * r.ix;
+    r.ly = (-o.y - r.pad) * r.iy; r.hy = (-o.y + r.pad) * r.iy;
+    r.lz = (-o.z - r.pad) * r.iz; r.hz = (-o.z + r.pad) * r.iz;
+    const float k = 1.0f / 262144.0f;
+    const float ex = k * (extent * fabsf(r.ix) + fabsf(r.lx) + fabsf(r.hx));
+    const float ey = k * (extent * fabsf(r.iy) + fabsf(r.ly) + fabsf(r.hy));
+    const float ez = k * (extent * fabsf(r.iz) + fabsf(r.lz) + fabsf(r.hz));
+    // d > 0: the lower plane is the entry (earlier by E), the upper one the exit (later by E); d < 0: the reverse
+    r.lx -= r.ix >= 0 ? ex : -ex; r.hx += r.ix >= 0 ? ex : -ex;
+    r.ly -= r.iy >= 0 ? ey : -ey; r.hy += r.iy >= 0 ? ey : -ey;
+    r.lz -= r.iz >= 0 ? ez : -ez; r.hz += r.iz >= 0 ? ez : -ez;
     return r;
 }
 
-RT_FN bool gate_maybe(const float* mn, const float* mx, f3 o, const RayGate& r)
+RT_FN bool gate_maybe(const float* mn, const float* mx, const RayGate& r)
 {
-    float ax = ((mn[0] - r.pad) - o.x) * r.ix, bx = ((mx[0] + r.pad) - o.x) * r.ix;
-    float ay = ((mn[1] - r.pad) - o.y) * r.iy, by = ((mx[1] + r.pad) - o.y) * r.iy;
-    float az = ((mn[2] - r.pad) - o.z) * r.iz, bz = ((mx[2] + r.pad) - o.z) * r.iz;
-    float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-    float f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    float slack = 8e-6f * fmaxf(fabsf(n), fabsf(f));
-    return (n - slack <= f + slack) && (f + slack >= 0.0f);
+    const float ax = fmaf(mn[0], r.ix, r.lx), bx = fmaf(mx[0], r.ix, r.hx);
+    const float ay = fmaf(mn[1], r.iy, r.ly), by = fmaf(mx[1], r.iy, r.hy);
+    const float az = fmaf(mn[2], r.iz, r.lz), bz = fmaf(mx[2], r.iz, r.hz);
+    const float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    return n <= f && f >= 0.0f;
 }
 
 // Conservative ACCEPT for the same gate.  box_intersects() is true as soon as ONE face test passes:
@@ -445,7 +460,7 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
             break;
         case G_GATED:
             if (STATS) cnt.gates++;
-            i = ((g.kind & G_SAME_BOX) || (gate_maybe(g.mn, g.mx, o, rg) && (gate_surely(g.mn, g.mx, o, d, rg) || box_intersects(g.mn, g.mx, o, d)))) ? i + 1 : g.skip;
+            i = ((g.kind & G_SAME_BOX) || (gate_maybe(g.mn, g.mx, rg) && (gate_surely(g.mn, g.mx, o, d, rg) || box_intersects(g.mn, g.mx, o, d)))) ? i + 1 : g.skip;
             break;
         case G_PLANE: {
             float t;
@@ -476,7 +491,7 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
         }
         default: { // G_MESH: gate, then defer its triangle BVH to the shared drain loop
             if (STATS) cnt.gates++;
-            if ((g.kind & G_SAME_BOX) || (gate_maybe(g.mn, g.mx, o, rg) && (gate_surely(g.mn, g.mx, o, d, rg) || box_intersects(g.mn, g.mx, o, d)))) {
+            if ((g.kind & G_SAME_BOX) || (gate_maybe(g.mn, g.mx, rg) && (gate_surely(g.mn, g.mx, o, d, rg) || box_intersects(g.mn, g.mx, o, d)))) {
                 st.p[(sp++) * st.stride] = g.a;
                 if (sp >= (DEFER ? RT_DEFER_ROOTS : RT_PENDING_MAX)) {
                     const RayCull rc = make_cull(S, o, d);

@@ -207,7 +207,7 @@ int emul_gate_check(uint32_t n, uint32_t seed, double* out)
         if ((it & 3) == 3) d = d * -1.0f;
         const RayGate rg = make_gate(cull_pad, ext, o, d);
         const bool exact = box_intersects(mn, mx, o, d);
-        const bool maybe = gate_maybe(mn, mx, o, rg);
+        const bool maybe = gate_maybe(mn, mx, rg);
         const bool surely = maybe && gate_surely(mn, mx, o, d, rg);
         cnt[0]++;
         if (!maybe) { cnt[1]++; if (exact) cnt[4]++; }
