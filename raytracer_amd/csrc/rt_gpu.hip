@@ -76,8 +76,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace(DScene S, RenderArgs A, Batc
     const uint32_t n = depth == 0 ? fixed_n : B.counters[C_QUEUE + depth];
     Stack st{s_stack + threadIdx.x, RT_BLOCK};
     Counters cnt{0, 0, 0, 0};
-    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK)
-        trace_item<STATS>(S, A, B, depth, i, st, cnt);
+    QCursor qc{0, 0};
+    // wave-uniform trip count: every lane of a wave takes part in the queue cursor's ballots
+    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        trace_item<STATS>(S, A, B, depth, i, i < n, st, cnt, qc);
+    }
+    close_cursor(qc, B.bq_roots, (uint32_t)REF_NONE, B.cq_cap);
     flush_counters<STATS>(cnt, B.stats, 0);
 }
 
@@ -186,7 +191,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
         return x;
     };
     uint32_t n = B.counters[counter];
-    if (n > B.bq_cap) n = B.bq_cap;
+    if (n > (AO ? B.bq_cap : B.cq_cap)) n = AO ? B.bq_cap : B.cq_cap;
     uint32_t* next = &B.counters[next_counter];
     uint32_t* pend = s_pend + threadIdx.x;
     Counters cnt{0, 0, 0, 0};
@@ -535,14 +540,18 @@ size_t carve_batch(Batch& B, char* base, uint32_t P, int levels, uint32_t nl, ui
     B.lvl = (q4*)take(sizeof(q4) * (size_t)P * levels);
     B.lvl_ph = (float*)take(4ull * P * levels * (nl > 1 ? nl - 1 : 1));
     B.lvl_kind = (uint8_t*)take((size_t)P * levels);
-    B.bq_cap = P * (n2 ? n2 : 1);
+    {   // closest-hit pass: one item per path at most, plus the holes of k_trace's chunked appends
+        const size_t waves = std::min<size_t>((size_t)RT_MAX_GRID * (RT_BLOCK / 64), ((size_t)P + 63) / 64);
+        B.cq_cap = (uint32_t)std::min<size_t>((size_t)P + waves * RT_QCHUNK + P / 16, 0xFFFF0000u);
+    }
+    B.bq_cap = B.cq_cap;
     if (n2) {   // room for the holes k_ao's chunked appends leave: one open chunk per wave + chunk tails
         const size_t rays = (size_t)P * n2, waves = std::min<size_t>((size_t)RT_MAX_GRID * (RT_BLOCK / 64), (rays + 63) / 64);
-        B.bq_cap = (uint32_t)std::min<size_t>(rays + waves * RT_QCHUNK + rays / 16, 0xFFFF0000u);
+        B.bq_cap = std::max(B.bq_cap, (uint32_t)std::min<size_t>(rays + waves * RT_QCHUNK + rays / 16, 0xFFFF0000u));
     }
     B.bq_a = (q4*)take(sizeof(q4) * (size_t)B.bq_cap);
     B.bq_b = (q4*)take(sizeof(q4) * (size_t)B.bq_cap);
-    B.bq_c = (q4*)take(sizeof(q4) * (size_t)P);
+    B.bq_c = (q4*)take(sizeof(q4) * (size_t)B.cq_cap);
     B.bq_roots = (uint32_t*)take(4ull * RT_DEFER_ROOTS * (size_t)B.bq_cap);
     B.bq_spill = (uint32_t*)take(4ull * (RT_STACK_DEPTH - RT_LDS_STACK) * RT_MAX_GRID * RT_BLOCK);
     return off;
@@ -888,7 +897,7 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
         tiles_per_batch = (tiles_per_batch + 1) / 2;
     }
     carve_batch(B, (char*)ctx->batch_mem, P, levels_alloc, nl, n2);
-    if (S.debug & 8u) B.bq_cap = std::min<uint32_t>(B.bq_cap, 3000u);   // test switch: a BVH queue that overflows (inline traversal path)
+    if (S.debug & 8u) { B.bq_cap = std::min<uint32_t>(B.bq_cap, 3000u); B.cq_cap = std::min<uint32_t>(B.cq_cap, 3000u); }   // test switch: a BVH queue that overflows (inline traversal path)
     B.counters = ctx->d_counters;
     B.stats = ctx->d_stats;
 

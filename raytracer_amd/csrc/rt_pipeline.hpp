@@ -52,6 +52,7 @@ struct Batch {
     uint32_t* bq_roots;    // [k * bq_cap + item]: mesh-BVH roots (their count rides in bq_b.w's top 3 bits); [item] == REF_NONE: hole
     uint32_t bq_cap;       // items the queue can hold (rays beyond it are traversed inline)
     uint32_t sh_cap;       // entries sh_queue can hold (holes of the chunked appends included)
+    uint32_t cq_cap;       // slots of the work queue the closest-hit pass may use (bq_c has this many; <= bq_cap)
     uint32_t* bq_spill;    // GPU: k_bvh's stack entries beyond its short LDS stack, [entry][global lane]
     uint32_t* counters;    // C_TOTAL
     unsigned long long* stats; // ST_TOTAL, accumulated over the whole render
@@ -134,26 +135,6 @@ RT_FN uint32_t item_path(const RenderArgs& A, const Batch& B, int depth, uint32_
     return depth == 0 ? idx : B.queue[depth & 1][idx];
 }
 
-// Queue a ray whose Mesh gates passed for the compacted BVH kernel; falls back to traversing
-// inline when the queue is full.  `best` is the closest hit among the non-mesh primitives.
-template <bool AO, bool STATS>
-RT_FN bool defer_bvh(const DScene& S, const Batch& B, uint32_t counter, f3 o, f3 d, Hit& best, uint32_t dst,
-                     Stack st, uint32_t sp, Counters& cnt)
-{
-    uint32_t slot = queue_slot(&B.counters[counter]);
-    if (slot >= B.bq_cap) {
-        RayCull rc = make_cull(S, o, d);
-        bvh_drain<STATS, false>(S, o, d, rc, best, st, sp, cnt);
-        return false;
-    }
-    q4 a = {o.x, o.y, o.z, best.t};
-    q4 b = {d.x, d.y, d.z, u2f(dst | ((sp - 1u) << 29))};   // dst < 2^29 (checked where the batch is sized); 1 <= sp <= RT_DEFER_ROOTS
-    B.bq_a[slot] = a; B.bq_b[slot] = b;
-    if (!AO) { q4 c = {u2f(best.prim), u2f(best.rank), best.u, best.v}; B.bq_c[slot] = c; }
-    for (uint32_t k = 0; k < sp; ++k) B.bq_roots[(size_t)k * B.bq_cap + slot] = st.p[k * st.stride];
-    return true;
-}
-
 // Chunked queue append for the GPU's hot queues.  A single counter word serves only ~90 returning
 // atomics per microsecond, so a wave reserves CHUNK consecutive slots with ONE atomic and hands
 // them out by ballot + prefix sum from a wave-uniform cursor.  Slots a wave reserves but never
@@ -200,34 +181,47 @@ RT_FN void close_cursor(const QCursor& qc, uint32_t* holes, uint32_t hole_value,
 #endif
 }
 
-// AO flavour of defer_bvh: one append per AO ray that meets a Mesh, through the chunked cursor.
-template <bool STATS>
-RT_FN bool defer_ao(const DScene& S, const Batch& B, uint32_t counter, bool want, f3 o, f3 d, Hit& best, uint32_t dst,
-                    Stack st, uint32_t sp, Counters& cnt, QCursor& qc)
+// Queue a ray whose Mesh gates passed for the compacted BVH kernel, through the chunked cursor (GPU: all 64
+// lanes of the wave call it, `want` selects); falls back to traversing inline when the queue is full.
+// `best` is the closest hit among the non-mesh primitives.  AO = 1: occlusion ray (no hit record travels).
+template <bool AO, bool STATS>
+RT_FN bool defer_bvh(const DScene& S, const Batch& B, uint32_t counter, bool want, f3 o, f3 d, Hit& best, uint32_t dst,
+                     Stack st, uint32_t sp, Counters& cnt, QCursor& qc)
 {
-    const uint32_t slot = chunk_append<RT_QCHUNK>(&B.counters[counter], want, qc, B.bq_roots, (uint32_t)REF_NONE, B.bq_cap);
+    const uint32_t cap = AO ? B.bq_cap : B.cq_cap;
+    const uint32_t slot = chunk_append<RT_QCHUNK>(&B.counters[counter], want, qc, B.bq_roots, (uint32_t)REF_NONE, cap);
     if (!want) return false;
-    if (slot >= B.bq_cap) {
+    if (slot >= cap) {
         RayCull rc = make_cull(S, o, d);
         bvh_drain<STATS, false>(S, o, d, rc, best, st, sp, cnt);
         return false;
     }
     q4 a = {o.x, o.y, o.z, best.t};
-    q4 b = {d.x, d.y, d.z, u2f(dst | ((sp - 1u) << 29))};
+    q4 b = {d.x, d.y, d.z, u2f(dst | ((sp - 1u) << 29))};   // dst < 2^29 (checked where the batch is sized); 1 <= sp <= RT_DEFER_ROOTS
     B.bq_a[slot] = a; B.bq_b[slot] = b;
+    if (!AO) { q4 c = {u2f(best.prim), u2f(best.rank), best.u, best.v}; B.bq_c[slot] = c; }
     for (uint32_t k = 0; k < sp; ++k) B.bq_roots[(size_t)k * B.bq_cap + slot] = st.p[k * st.stride];
     return true;
 }
 
+// GPU: called by all 64 lanes of a wave (`valid` = false for lanes without an item): the queue cursor votes
 template <bool STATS>
-RT_FN void trace_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, Stack st, Counters& cnt)
+RT_FN void trace_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, bool valid, Stack st, Counters& cnt, QCursor& qc)
 {
-    uint32_t p = item_path(A, B, depth, idx);
-    if (depth == 0 && !path_of(A, p).valid) return;
-    q4 o4 = B.ray_o[depth & 1][p], d4 = B.ray_d[depth & 1][p];
-    Hit h; float sh;
-    uint32_t sp = trace<0, STATS, true>(S, xyz(o4), xyz(d4), FLT_MAX, h, sh, st, cnt);
-    if (sp > 0 && defer_bvh<false, STATS>(S, B, C_BQ + depth, xyz(o4), xyz(d4), h, p, st, sp, cnt)) return;
+    uint32_t p = 0, sp = 0;
+    f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
+    Hit h = {}; float sh;
+    if (valid) {
+        p = item_path(A, B, depth, idx);
+        valid = !(depth == 0 && !path_of(A, p).valid);
+    }
+    if (valid) {
+        const q4 o4 = B.ray_o[depth & 1][p], d4 = B.ray_d[depth & 1][p];
+        o = xyz(o4); d = xyz(d4);
+        sp = trace<0, STATS, true>(S, o, d, FLT_MAX, h, sh, st, cnt);
+    }
+    if (defer_bvh<false, STATS>(S, B, C_BQ + depth, sp > 0, o, d, h, p, st, sp, cnt, qc)) return;
+    if (!valid) return;
     q4 r = {h.t, u2f(h.prim), h.u, h.v};
     B.hit[p] = r;
 }
@@ -406,7 +400,7 @@ RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int dep
             sp = trace<0, STATS, true>(S, o, dir, S.ambient.occlusion_dist, h, sh, st, cnt);
         }
     }
-    if (defer_ao<STATS>(S, B, C_BQA + depth, sp > 0, o, dir, h, dst, st, sp, cnt, qc)) return;
+    if (defer_bvh<true, STATS>(S, B, C_BQA + depth, sp > 0, o, dir, h, dst, st, sp, cnt, qc)) return;
     if (valid) B.ao_t[dst] = h.t;   // stays occlusion_dist when nothing closer was found
 }
 

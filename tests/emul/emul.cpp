@@ -25,11 +25,12 @@ struct LoopBackend {
     uint32_t count(int d, uint32_t fixed) { return d == 0 ? fixed : B.counters[C_QUEUE + d]; }
     void trace(const RenderArgs& A, int d, uint32_t fixed) {
         Stack st{stack.data(), 1};
-        for (uint32_t i = 0, n = count(d, fixed); i < n; ++i) trace_item<true>(S, A, B, d, i, st, cnt[0]);
+        QCursor qc{0, 0};
+        for (uint32_t i = 0, n = count(d, fixed); i < n; ++i) trace_item<true>(S, A, B, d, i, true, st, cnt[0], qc);
     }
     void bvh_trace(const RenderArgs& A, int d) {
         Stack st{stack.data(), 1};
-        for (uint32_t i = 0, n = std::min(B.counters[C_BQ + d], B.bq_cap); i < n; ++i) bvh_item<false, true>(S, B, i, st, cnt[0]);
+        for (uint32_t i = 0, n = std::min(B.counters[C_BQ + d], B.cq_cap); i < n; ++i) bvh_item<false, true>(S, B, i, st, cnt[0]);
     }
     void bvh_ao(const RenderArgs& A, int d) {
         Stack st{stack.data(), 1};
@@ -120,6 +121,7 @@ int emul_render(const rt_scene_desc* d, const rt_camera* cam, const rt_params* p
     // a deliberately small queue so the inline fallback of defer_bvh is exercised too
     std::vector<q4> aoo(P), aou(P), aow(P);
     B.bq_cap = P * (n2 ? n2 : 1) / 3 + 1;
+    B.cq_cap = B.bq_cap;
     B.sh_cap = (uint32_t)shq.size();
     std::vector<q4> bqa(B.bq_cap), bqb(B.bq_cap), bqc(B.bq_cap); std::vector<uint32_t> bqr((size_t)B.bq_cap * RT_DEFER_ROOTS);
     B.bq_a = bqa.data(); B.bq_b = bqb.data(); B.bq_c = bqc.data(); B.bq_roots = bqr.data();
