@@ -142,8 +142,12 @@ RT_FN uint32_t item_path(const RenderArgs& A, const Batch& B, int depth, uint32_
 // skips them.  Must be called by all 64 lanes of the wave (`want` selects).  Returns the slot of a
 // lane that wants one; a slot >= cap must not be written.
 struct QCursor { uint32_t next, end; };
-#define RT_QCHUNK 1024u    // BVH work queue (k_ao)
-#define RT_SHCHUNK 256u    // shadow queue (k_prep)
+#ifndef RT_QCHUNK
+#define RT_QCHUNK 1024u    // BVH work queue (k_trace, k_ao)
+#endif
+#ifndef RT_SHCHUNK
+#define RT_SHCHUNK 512u    // shadow queue (k_prep); 256: k_prep +1.2 ms, 1024: k_shadow +0.5 ms (more holes)
+#endif
 #define RT_AO_BLOCK 4096u   // slots per block of the AO kernel's blocked stratum-major order (power of two)
 
 template <uint32_t CHUNK>
