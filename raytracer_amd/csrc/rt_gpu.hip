@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace(DScene S, RenderArgs A, Batc
     const uint32_t n = depth == 0 ? fixed_n : B.counters[C_QUEUE + depth];
     Stack st{s_stack + threadIdx.x, RT_BLOCK};
     Counters cnt{0, 0, 0, 0};
-    QCursor qc{0, 0};
+    QCursor qc{0, 0, queue_chunk(n, gridDim.x * (RT_BLOCK / 64), RT_QCHUNK)};
     // wave-uniform trip count: every lane of a wave takes part in the queue cursor's ballots
     for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
         const uint32_t i = base + threadIdx.x;
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace(DScene S, RenderArgs A, Batc
 __global__ void __launch_bounds__(RT_BLOCK) k_prep(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
 {
     const uint32_t n = depth == 0 ? fixed_n : B.counters[C_QUEUE + depth];
-    QCursor qsh{0, 0};
+    QCursor qsh{0, 0, queue_chunk((uint64_t)n * S.num_lights, gridDim.x * (RT_BLOCK / 64), RT_SHCHUNK)};
     // wave-uniform trip count: every lane of a wave takes part in the queue cursor's ballots
     for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
         const uint32_t i = base + threadIdx.x;
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B
     const uint32_t n = nslots * n2;
     Stack st{s_stack + threadIdx.x, RT_BLOCK};
     Counters cnt{0, 0, 0, 0};
-    QCursor qc{0, 0};
+    QCursor qc{0, 0, queue_chunk(n, gridDim.x * (RT_BLOCK / 64), RT_QCHUNK)};
     // wave-uniform trip count: every lane of a wave takes part in the queue cursor's ballots
     for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
         const uint32_t i = base + threadIdx.x;
@@ -192,6 +192,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
     };
     uint32_t n = B.counters[counter];
     if (n > (AO ? B.bq_cap : B.cq_cap)) n = AO ? B.bq_cap : B.cq_cap;
+    // a wave takes at least 64 items, so waves beyond ceil(n/64) have nothing to fetch: they leave before touching
+    // the queue counter (the launches of the deeper levels of a small frame hold a few hundred rays for 8192 waves)
+    if ((uint64_t)(blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6)) * 64u >= n) return;
     uint32_t* next = &B.counters[next_counter];
     uint32_t* pend = s_pend + threadIdx.x;
     Counters cnt{0, 0, 0, 0};

@@ -141,7 +141,18 @@ RT_FN uint32_t item_path(const RenderArgs& A, const Batch& B, int depth, uint32_
 // fills (the tail of a chunk) are marked as holes (`hole_value` in `holes[slot]`); the consumer
 // skips them.  Must be called by all 64 lanes of the wave (`want` selects).  Returns the slot of a
 // lane that wants one; a slot >= cap must not be written.
-struct QCursor { uint32_t next, end; };
+struct QCursor { uint32_t next, end, chunk = 0; };   // chunk 0 = the queue's largest chunk
+
+// Chunk size of one launch (wave-uniform): every wave leaves up to one chunk of holes behind, which the consumer
+// has to step over, so a launch whose waves append few items each (small frames, deep levels) takes small chunks:
+// about an eighth of a wave's expected appends, a power of two in [64, largest].
+RT_FN uint32_t queue_chunk(uint64_t appends, uint32_t waves, uint32_t largest)
+{
+    const uint64_t per_wave = appends / (waves ? waves : 1u) / 8u;
+    uint32_t c = 64u;
+    while (c < largest && c * 2u <= per_wave) c *= 2u;
+    return c;
+}
 #ifndef RT_QCHUNK
 #define RT_QCHUNK 1024u    // BVH work queue (k_trace, k_ao)
 #endif
@@ -150,6 +161,7 @@ struct QCursor { uint32_t next, end; };
 #endif
 #define RT_AO_BLOCK 4096u   // slots per block of the AO kernel's blocked stratum-major order (power of two)
 
+// CHUNK is the largest chunk; qc.chunk (queue_chunk() below) is what the launch uses.
 template <uint32_t CHUNK>
 RT_FN uint32_t chunk_append(uint32_t* counter, bool want, QCursor& qc, uint32_t* holes, uint32_t hole_value, uint32_t cap)
 {
@@ -162,9 +174,10 @@ RT_FN uint32_t chunk_append(uint32_t* counter, bool want, QCursor& qc, uint32_t*
         const uint32_t rem = qc.end - qc.next;   // < 64
         if (lane < rem && qc.next + lane < cap) holes[qc.next + lane] = hole_value;
         uint32_t b0 = 0;
-        if (lane == 0) b0 = atomicAdd(counter, CHUNK);
+        const uint32_t chunk = qc.chunk ? qc.chunk : CHUNK;
+        if (lane == 0) b0 = atomicAdd(counter, chunk);
         b0 = __shfl(b0, 0);
-        qc.next = b0; qc.end = b0 + CHUNK;
+        qc.next = b0; qc.end = b0 + chunk;
     }
     const uint32_t slot = qc.next + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
     qc.next += nw;
