@@ -145,10 +145,10 @@ struct QCursor { uint32_t next, end, chunk = 0; };   // chunk 0 = the queue's la
 
 // Chunk size of one launch (wave-uniform): every wave leaves up to one chunk of holes behind, which the consumer
 // has to step over, so a launch whose waves append few items each (small frames, deep levels) takes small chunks:
-// about an eighth of a wave's expected appends, a power of two in [64, largest].
+// about a quarter of a wave's expected appends, a power of two in [64, largest].
 RT_FN uint32_t queue_chunk(uint64_t appends, uint32_t waves, uint32_t largest)
 {
-    const uint64_t per_wave = appends / (waves ? waves : 1u) / 8u;
+    const uint64_t per_wave = appends / (waves ? waves : 1u) / 4u;
     uint32_t c = 64u;
     while (c < largest && c * 2u <= per_wave) c *= 2u;
     return c;
