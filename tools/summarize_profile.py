@@ -25,9 +25,10 @@ def short(name):
     return m.group(1) if m else name[:40]
 
 
-st = glob.glob(os.path.join(G, f"{tag}_stats", "*", "*_kernel_stats.csv"))
+# a tag profiled twice leaves both runs' files in gpurun_out/ (gpurun merges): take the newest
+st = sorted(glob.glob(os.path.join(G, f"{tag}_stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
 if st:
-    df = pd.read_csv(st[0])
+    df = pd.read_csv(st[-1])
     df["Name"] = df["Name"].map(short)
     df.to_csv(os.path.join(P, f"{tag}_kernel_stats.csv"), index=False)
     print(df[["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"]].to_string(index=False))
@@ -39,10 +40,10 @@ if st:
 
 rows = []
 for sub in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq", "pmc_sq2", "pmc_ta"):
-    f = glob.glob(os.path.join(G, f"{tag}_{sub}", "*", "*_counter_collection.csv"))
+    f = sorted(glob.glob(os.path.join(G, f"{tag}_{sub}", "*", "*_counter_collection.csv")), key=os.path.getmtime)
     if not f:
         continue
-    df = pd.read_csv(f[0])
+    df = pd.read_csv(f[-1])
     df["k"] = df["Kernel_Name"].map(short)
     g = df.groupby(["k", "Counter_Name"])["Counter_Value"].agg(["sum", "count"]).reset_index()
     rows.append(g)
