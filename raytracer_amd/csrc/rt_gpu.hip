@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B
 #define RT_BVH_CHUNK 512
 #endif
 #ifndef RT_REFILL_IDLE
-#define RT_REFILL_IDLE 32    // refill once this many lanes hold no ray
+#define RT_REFILL_IDLE 40    // refill once this many lanes hold no ray
 #endif
 #ifndef RT_PEND
 #define RT_PEND 2            // parked leaves per lane
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B
 #endif
 #ifndef RT_REP_NUM
 #define RT_REP_NUM 1         // repeat while RT_REP_NUM/RT_REP_DEN of the voters are ready again
-#define RT_REP_DEN 2
+#define RT_REP_DEN 4
 #endif
 #ifndef RT_LDS_STACK
 #define RT_LDS_STACK 12      // stack entries per lane kept in LDS; deeper ones spill to global memory (rare)
