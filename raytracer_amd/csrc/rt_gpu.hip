@@ -24,8 +24,34 @@
 
 using namespace rt;
 
+#ifndef RT_BLOCK
 #define RT_BLOCK 256
-#define RT_MAX_GRID (256 * 8)
+#endif
+#ifndef RT_MAX_GRID
+#define RT_MAX_GRID (256 * 8)   // persistent k_bvh, and the default of the grid-stride kernels
+#endif
+// Grid-stride kernels: a grid slightly above what is resident at once ends in a thin second round of blocks, so
+// a kernel launches either what fits in one round (even work per item: k_prep, k_shade at 7 waves/SIMD hold 1792
+// blocks; 1536 measured best) or many rounds of short blocks that the dispatcher balances (uneven work per item:
+// the gate walks).  Measured on config 3 (ms per frame): k_ao 55.3 / 52.3 / 50.0 / 48.8 / 46.3 / 51.0 at 2048 /
+// 4096 / 8192 / 16384 / 32768 / 65536 blocks; k_shadow 11.6 / 11.2 / 11.0 at 2048 / 4096 / 8192; k_prep 5.3 -> 4.8
+// and k_shade 4.7 -> 4.0 at 1536; k_trace best at 2048.
+#ifndef RT_GRID_TRACE
+#define RT_GRID_TRACE RT_MAX_GRID
+#endif
+#ifndef RT_GRID_PREP
+#define RT_GRID_PREP 1536
+#endif
+#ifndef RT_GRID_SHADOW
+#define RT_GRID_SHADOW 8192
+#endif
+#ifndef RT_GRID_AO
+#define RT_GRID_AO 32768
+#endif
+#ifndef RT_GRID_SHADE
+#define RT_GRID_SHADE 1536
+#endif
+constexpr uint32_t rt_max_u32(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
 // ---- kernels -------------------------------------------------------------------------------------
 // cls 0 closest-hit queries, 1 shadow rays, 2 AO rays.  The ray counts (cls 1, 2) are always kept;
@@ -437,11 +463,11 @@ static std::string g_init_error;
         }                                                                                        \
     } while (0)
 
-static inline uint32_t grid_for(uint64_t n)
+static inline uint32_t grid_for(uint64_t n, uint32_t cap = RT_MAX_GRID)
 {
     uint64_t b = (n + RT_BLOCK - 1) / RT_BLOCK;
     if (b < 1) b = 1;
-    return (uint32_t)(b > RT_MAX_GRID ? RT_MAX_GRID : b);
+    return (uint32_t)(b > cap ? cap : b);
 }
 
 // ---- HIP launcher backend of render_frame -------------------------------------------------------------
@@ -477,12 +503,20 @@ struct GpuBackend {
         if (r != hipSuccess) err = r;
     }
     void raygen(const RenderArgs& A, uint32_t n) { timed(RT_K_RAYGEN, [&] { hipLaunchKernelGGL(k_raygen, dim3(grid_for(n)), dim3(RT_BLOCK), 0, stream, S, A, B, n); }); }
-    uint32_t grid_d(int d, uint32_t n) { return d == 0 ? grid_for(n) : RT_MAX_GRID; }
+    // many short blocks for the uneven kernels, but at least 16 items per thread (small frames: the per-block set-up
+    // and the per-wave queue chunks would dominate), and never fewer blocks than the default grid offers
+    static uint32_t grid_many(uint64_t items, uint32_t cap)
+    {
+        const uint32_t lo = grid_for(items, RT_MAX_GRID), want = grid_for(items / 16, cap);
+        return want > lo ? want : lo;
+    }
+    // n = paths of the batch: the item count at depth 0 and an upper bound of the device-side counts below it
+    uint32_t grid_d(int, uint32_t n, uint32_t cap) { return grid_for(n, cap); }
     void trace(const RenderArgs& A, int d, uint32_t n)
     {
         timed(RT_K_TRACE, [&] {
-            if (stats) hipLaunchKernelGGL(k_trace<true>, dim3(grid_d(d, n)), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
-            else hipLaunchKernelGGL(k_trace<false>, dim3(grid_d(d, n)), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
+            if (stats) hipLaunchKernelGGL(k_trace<true>, dim3(grid_d(d, n, RT_GRID_TRACE)), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
+            else hipLaunchKernelGGL(k_trace<false>, dim3(grid_d(d, n, RT_GRID_TRACE)), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
         });
     }
     void bvh_trace(const RenderArgs& A, int d)
@@ -500,24 +534,26 @@ struct GpuBackend {
             else hipLaunchKernelGGL((k_bvh<true, false>), dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, B, C_BQA + d, C_BQA_NEXT + d);
         });
     }
-    void prep(const RenderArgs& A, int d, uint32_t n) { timed(RT_K_PREP, [&] { hipLaunchKernelGGL(k_prep, dim3(grid_d(d, n)), dim3(RT_BLOCK), 0, stream, S, A, B, d, n); }); }
+    void prep(const RenderArgs& A, int d, uint32_t n) { timed(RT_K_PREP, [&] { hipLaunchKernelGGL(k_prep, dim3(grid_d(d, n, RT_GRID_PREP)), dim3(RT_BLOCK), 0, stream, S, A, B, d, n); }); }
     void shadow(const RenderArgs& A, int d)
     {
         if (S.num_lights == 0) return;
+        const uint32_t g = grid_many((uint64_t)B.P * S.num_lights, d == 0 ? RT_GRID_SHADOW : RT_MAX_GRID);   // the queue cannot hold more than this; deeper levels are usually short
         timed(RT_K_SHADOW, [&] {
-            if (stats) hipLaunchKernelGGL(k_shadow<true>, dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, A, B, d);
-            else hipLaunchKernelGGL(k_shadow<false>, dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, A, B, d);
+            if (stats) hipLaunchKernelGGL(k_shadow<true>, dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d);
+            else hipLaunchKernelGGL(k_shadow<false>, dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d);
         });
     }
     void ao(const RenderArgs& A, int d, uint32_t n)
     {
         if (S.ambient.occlusion_samples <= 0) return;
+        const uint32_t g = grid_many((uint64_t)n * (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples), d == 0 ? RT_GRID_AO : RT_MAX_GRID);
         timed(RT_K_AO, [&] {
-            if (stats) hipLaunchKernelGGL(k_ao<true>, dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
-            else hipLaunchKernelGGL(k_ao<false>, dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
+            if (stats) hipLaunchKernelGGL(k_ao<true>, dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
+            else hipLaunchKernelGGL(k_ao<false>, dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
         });
     }
-    void shade(const RenderArgs& A, int d, uint32_t n) { timed(RT_K_SHADE, [&] { hipLaunchKernelGGL(k_shade, dim3(grid_d(d, n)), dim3(RT_BLOCK), 0, stream, S, A, B, d, n); }); }
+    void shade(const RenderArgs& A, int d, uint32_t n) { timed(RT_K_SHADE, [&] { hipLaunchKernelGGL(k_shade, dim3(grid_d(d, n, RT_GRID_SHADE)), dim3(RT_BLOCK), 0, stream, S, A, B, d, n); }); }
     void resolve(const RenderArgs& A, uint32_t n) { timed(RT_K_RESOLVE, [&] { hipLaunchKernelGGL(k_resolve, dim3(grid_for(n)), dim3(RT_BLOCK), 0, stream, S, A, B, n, levels_run); }); }
 };
 
@@ -535,22 +571,25 @@ size_t carve_batch(Batch& B, char* base, uint32_t P, int levels, uint32_t nl, ui
     B.pstate = (uint32_t*)take(4ull * P);
     B.ao_o = (q4*)take(sizeof(q4) * P); B.ao_u = (q4*)take(sizeof(q4) * P); B.ao_w = (q4*)take(sizeof(q4) * P);
     B.ao_slot = (uint32_t*)take(4ull * P);
-    // worst case of the chunked appends: <= 63 holes per RT_SHCHUNK-slot chunk + one open chunk per wave of k_prep
-    B.sh_cap = (uint32_t)std::min<size_t>((size_t)P * nl * RT_SHCHUNK / (RT_SHCHUNK - 63) + RT_SHCHUNK + (size_t)RT_MAX_GRID * (RT_BLOCK / 64) * RT_SHCHUNK, 0xFFFF0000u);
+    // Worst case of k_prep's chunked appends: an append wastes the rest of the wave's chunk only when that rest is
+    // smaller than the append itself, so holes < items; plus one open chunk per wave.  (A shadow ray that found no
+    // slot would be lost, so this bound is the true worst case; the BVH queues below fall back to inline traversal.)
+    B.sh_cap = (uint32_t)std::min<size_t>(2 * (size_t)P * nl + (size_t)RT_GRID_PREP * (RT_BLOCK / 64) * RT_SHCHUNK, 0xFFFF0000u);
     B.sh_queue = (uint32_t*)take(4ull * B.sh_cap);
     B.ao_t = (float*)take(4ull * P * (n2 ? n2 : 1));
     B.sh_res = (float*)take(4ull * P * nl);
     B.lvl = (q4*)take(sizeof(q4) * (size_t)P * levels);
     B.lvl_ph = (float*)take(4ull * P * levels * (nl > 1 ? nl - 1 : 1));
     B.lvl_kind = (uint8_t*)take((size_t)P * levels);
-    {   // closest-hit pass: one item per path at most, plus the holes of k_trace's chunked appends
-        const size_t waves = std::min<size_t>((size_t)RT_MAX_GRID * (RT_BLOCK / 64), ((size_t)P + 63) / 64);
-        B.cq_cap = (uint32_t)std::min<size_t>((size_t)P + waves * RT_QCHUNK + P / 16, 0xFFFF0000u);
+    {   // closest-hit pass: one item per path at most, plus the holes of k_trace's chunked appends (one open chunk per wave + chunk tails)
+        const uint32_t waves = (uint32_t)std::min<size_t>((size_t)RT_GRID_TRACE * (RT_BLOCK / 64), ((size_t)P + 63) / 64);
+        B.cq_cap = (uint32_t)std::min<size_t>((size_t)P + (size_t)waves * queue_chunk(P, waves, RT_QCHUNK) + P / 8, 0xFFFF0000u);
     }
     B.bq_cap = B.cq_cap;
-    if (n2) {   // room for the holes k_ao's chunked appends leave: one open chunk per wave + chunk tails
-        const size_t rays = (size_t)P * n2, waves = std::min<size_t>((size_t)RT_MAX_GRID * (RT_BLOCK / 64), (rays + 63) / 64);
-        B.bq_cap = std::max(B.bq_cap, (uint32_t)std::min<size_t>(rays + waves * RT_QCHUNK + rays / 16, 0xFFFF0000u));
+    if (n2) {   // the same for k_ao
+        const size_t rays = (size_t)P * n2;
+        const uint32_t waves = (uint32_t)std::min<size_t>((size_t)RT_GRID_AO * (RT_BLOCK / 64), (rays + 63) / 64);
+        B.bq_cap = std::max(B.bq_cap, (uint32_t)std::min<size_t>(rays + (size_t)waves * queue_chunk(rays, waves, RT_QCHUNK) + rays / 8, 0xFFFF0000u));
     }
     B.bq_a = (q4*)take(sizeof(q4) * (size_t)B.bq_cap);
     B.bq_b = (q4*)take(sizeof(q4) * (size_t)B.bq_cap);

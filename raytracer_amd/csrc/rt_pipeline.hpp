@@ -159,7 +159,9 @@ RT_FN uint32_t queue_chunk(uint64_t appends, uint32_t waves, uint32_t largest)
 #ifndef RT_SHCHUNK
 #define RT_SHCHUNK 512u    // shadow queue (k_prep); 256: k_prep +1.2 ms, 1024: k_shadow +0.5 ms (more holes)
 #endif
+#ifndef RT_AO_BLOCK
 #define RT_AO_BLOCK 4096u   // slots per block of the AO kernel's blocked stratum-major order (power of two)
+#endif
 
 // CHUNK is the largest chunk; qc.chunk (queue_chunk() below) is what the launch uses.
 template <uint32_t CHUNK>
