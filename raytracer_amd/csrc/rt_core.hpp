@@ -96,6 +96,7 @@ struct DScene {
     // kernel arguments sit in constant memory, so a closest-hit walk reads them with scalar loads in a
     // wave-uniform loop instead of interpreting gate nodes.  {point, normal, bits(rank), bits(plane index)}
     uint32_t num_lead_planes;
+    uint32_t lead_axis;   // 4 bits per lead plane: 0..2 = the normal is +-(that unit axis) exactly, 3 = any other normal
     float lead_planes[RT_LEAD_PLANES][8];
 };
 
@@ -127,6 +128,17 @@ RT_FN bool plane_t(f3 point, f3 normal, f3 o, f3 d, float& t)
     float denom = dot(normal, d);
     if (fabsf(denom) < 0.00001f) return false;
     float tt = dot(point - o, normal) / denom;
+    if (tt >= 0 && tt < FLT_MAX) { t = tt; return true; }
+    return false;
+}
+
+// plane_t for a normal that is exactly +-(a unit axis): the reference's dot products reduce exactly (finite rays:
+// the other terms are +-0) to denom = +-d[a] and dot(p - o, n) = +-(p[a] - o[a]) with the same sign, and IEEE
+// division is symmetric in sign, so t = (p[a] - o[a]) / d[a] has the bits of the general evaluation.
+RT_FN bool plane_axis_t(float pa, float oa, float da, float& t)
+{
+    if (fabsf(da) < 0.00001f) return false;
+    float tt = (pa - oa) / da;
     if (tt >= 0 && tt < FLT_MAX) { t = tt; return true; }
     return false;
 }
@@ -432,7 +444,14 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
         for (uint32_t j = 0; j < S.num_lead_planes; ++j) {
             const float* pl = S.lead_planes[j];
             float t;
-            if (plane_t(F3(pl[0], pl[1], pl[2]), F3(pl[3], pl[4], pl[5]), o, d, t) && closer(t, f2u(pl[6]), best)) {
+            bool hit;
+            switch ((S.lead_axis >> (4u * j)) & 15u) {   // wave-uniform
+            case 0: hit = plane_axis_t(pl[0], o.x, d.x, t); break;
+            case 1: hit = plane_axis_t(pl[1], o.y, d.y, t); break;
+            case 2: hit = plane_axis_t(pl[2], o.z, d.z, t); break;
+            default: hit = plane_t(F3(pl[0], pl[1], pl[2]), F3(pl[3], pl[4], pl[5]), o, d, t); break;
+            }
+            if (hit && closer(t, f2u(pl[6]), best)) {
                 best.t = t; best.prim = H_PLANE | f2u(pl[7]); best.rank = f2u(pl[6]);
             }
         }

@@ -650,12 +650,18 @@ bool HostScene::subtree_opaque(const rt_shape_ref& r)
 void HostScene::fill_lead_planes(DScene& D) const
 {
     D.num_lead_planes = 0;
+    D.lead_axis = 0;
     for (size_t i = 0; i < gates.size() && i < RT_LEAD_PLANES; ++i) {
         const GateNode& g = gates[i];
         if ((g.kind & G_KIND_MASK) != G_PLANE) break;   // top-level nodes come first; a plane inside a BVHAccel follows a gated node
         float* pl = D.lead_planes[D.num_lead_planes++];
         std::memcpy(pl, g.mn, 12); std::memcpy(pl + 3, g.mx, 12);
         pl[6] = u2f(g.rank); pl[7] = u2f(g.a);
+        // normal exactly +-(unit axis)?  (-0 components count as 0)
+        uint32_t axis = 3;
+        for (uint32_t k = 0; k < 3; ++k)
+            if (std::fabs(g.mx[k]) == 1.0f && g.mx[(k + 1) % 3] == 0.0f && g.mx[(k + 2) % 3] == 0.0f) axis = k;
+        D.lead_axis |= axis << (4u * (D.num_lead_planes - 1));
     }
 }
 
