@@ -195,24 +195,30 @@ __global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B
 #define RT_LDS_STACK 12      // stack entries per lane kept in LDS; deeper ones spill to global memory (rare)
 #endif
 
+#ifndef RT_BVH_BLOCK
+#define RT_BVH_BLOCK RT_BLOCK   // threads per block and blocks of the persistent kernel
+#endif
+#ifndef RT_BVH_GRID
+#define RT_BVH_GRID RT_MAX_GRID
+#endif
 template <bool AO, bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter, int next_counter)
+__global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int counter, int next_counter)
 {
-    __shared__ uint32_t s_stack[RT_LDS_STACK * RT_BLOCK];
-    __shared__ uint32_t s_pend[RT_PEND * RT_BLOCK];
+    __shared__ uint32_t s_stack[RT_LDS_STACK * RT_BVH_BLOCK];
+    __shared__ uint32_t s_pend[RT_PEND * RT_BVH_BLOCK];
     // volatile: keeps the (rare) global spill accesses from being merged with the LDS ones into
     // generic-pointer (flat) instructions, which wait on both memory counters
-    volatile uint32_t* const spill = B.bq_spill + (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;
-    const size_t spill_stride = (size_t)RT_MAX_GRID * RT_BLOCK;
+    volatile uint32_t* const spill = B.bq_spill + (size_t)blockIdx.x * RT_BVH_BLOCK + threadIdx.x;
+    const size_t spill_stride = (size_t)RT_BVH_GRID * RT_BVH_BLOCK;
     auto push = [&](uint32_t& sp_, uint32_t x) {
-        if (sp_ < RT_LDS_STACK) s_stack[sp_ * RT_BLOCK + threadIdx.x] = x;
+        if (sp_ < RT_LDS_STACK) s_stack[sp_ * RT_BVH_BLOCK + threadIdx.x] = x;
         else if (sp_ < RT_STACK_DEPTH) spill[(size_t)(sp_ - RT_LDS_STACK) * spill_stride] = x;
         else return;
         ++sp_;
     };
     auto pop = [&](uint32_t& sp_) -> uint32_t {
         --sp_;
-        uint32_t x = s_stack[(sp_ < RT_LDS_STACK ? sp_ : RT_LDS_STACK - 1) * RT_BLOCK + threadIdx.x];
+        uint32_t x = s_stack[(sp_ < RT_LDS_STACK ? sp_ : RT_LDS_STACK - 1) * RT_BVH_BLOCK + threadIdx.x];
         if (sp_ >= RT_LDS_STACK) x = spill[(size_t)(sp_ - RT_LDS_STACK) * spill_stride];
         return x;
     };
@@ -220,7 +226,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
     if (n > (AO ? B.bq_cap : B.cq_cap)) n = AO ? B.bq_cap : B.cq_cap;
     // a wave takes at least 64 items, so waves beyond ceil(n/64) have nothing to fetch: they leave before touching
     // the queue counter (the launches of the deeper levels of a small frame hold a few hundred rays for 8192 waves)
-    if ((uint64_t)(blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6)) * 64u >= n) return;
+    if ((uint64_t)(blockIdx.x * (RT_BVH_BLOCK / 64) + (threadIdx.x >> 6)) * 64u >= n) return;
     uint32_t* next = &B.counters[next_counter];
     uint32_t* pend = s_pend + threadIdx.x;
     Counters cnt{0, 0, 0, 0};
@@ -313,14 +319,14 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
                         c0 = cur;   // a leaf that arrived as a root or waited for room
                     }
                     // leaves are parked for the triangle steps; inner nodes continue the descent
-                    if (c0 != REF_NONE && (c0 & REF_LEAF) && npend < RT_PEND) { pend[(npend++) * RT_BLOCK] = c0; c0 = REF_NONE; }
-                    if (c1 != REF_NONE && (c1 & REF_LEAF) && npend < RT_PEND) { pend[(npend++) * RT_BLOCK] = c1; c1 = REF_NONE; }
+                    if (c0 != REF_NONE && (c0 & REF_LEAF) && npend < RT_PEND) { pend[(npend++) * RT_BVH_BLOCK] = c0; c0 = REF_NONE; }
+                    if (c1 != REF_NONE && (c1 & REF_LEAF) && npend < RT_PEND) { pend[(npend++) * RT_BVH_BLOCK] = c1; c1 = REF_NONE; }
                     if (c0 == REF_NONE) { c0 = c1; c1 = REF_NONE; }
                     if (c1 != REF_NONE) push(sp, c1);
                     cur = c0;
                     while (cur == REF_NONE && sp > 0) {   // pop; leaves that come off the stack are parked right away
                         const uint32_t x = pop(sp);
-                        if ((x & REF_LEAF) && npend < RT_PEND) pend[(npend++) * RT_BLOCK] = x;
+                        if ((x & REF_LEAF) && npend < RT_PEND) pend[(npend++) * RT_BVH_BLOCK] = x;
                         else cur = x;
                     }
                 }
@@ -334,7 +340,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bvh(DScene S, Batch B, int counter
                 if (STATS && AO) { dg[2]++; dg[3] += (uint32_t)__popcll(__ballot(ct)); }
                 if (ct) {
                     if (tri_left == 0) {
-                        const uint32_t ref = pend[(--npend) * RT_BLOCK];
+                        const uint32_t ref = pend[(--npend) * RT_BVH_BLOCK];
                         tri_next = ref & 0x0FFFFFFFu; tri_left = ((ref >> 28) & 7u) + 1u;
                     }
                     const q4* T = S.tris + (size_t)tri_next * 3;
@@ -522,16 +528,16 @@ struct GpuBackend {
     void bvh_trace(const RenderArgs& A, int d)
     {
         timed(RT_K_TRACE_BVH, [&] {
-            if (stats) hipLaunchKernelGGL((k_bvh<false, true>), dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, B, C_BQ + d, C_BQ_NEXT + d);
-            else hipLaunchKernelGGL((k_bvh<false, false>), dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, B, C_BQ + d, C_BQ_NEXT + d);
+            if (stats) hipLaunchKernelGGL((k_bvh<false, true>), dim3(RT_BVH_GRID), dim3(RT_BVH_BLOCK), 0, stream, S, B, C_BQ + d, C_BQ_NEXT + d);
+            else hipLaunchKernelGGL((k_bvh<false, false>), dim3(RT_BVH_GRID), dim3(RT_BVH_BLOCK), 0, stream, S, B, C_BQ + d, C_BQ_NEXT + d);
         });
     }
     void bvh_ao(const RenderArgs& A, int d)
     {
         if (S.ambient.occlusion_samples <= 0) return;
         timed(RT_K_AO_BVH, [&] {
-            if (stats) hipLaunchKernelGGL((k_bvh<true, true>), dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, B, C_BQA + d, C_BQA_NEXT + d);
-            else hipLaunchKernelGGL((k_bvh<true, false>), dim3(RT_MAX_GRID), dim3(RT_BLOCK), 0, stream, S, B, C_BQA + d, C_BQA_NEXT + d);
+            if (stats) hipLaunchKernelGGL((k_bvh<true, true>), dim3(RT_BVH_GRID), dim3(RT_BVH_BLOCK), 0, stream, S, B, C_BQA + d, C_BQA_NEXT + d);
+            else hipLaunchKernelGGL((k_bvh<true, false>), dim3(RT_BVH_GRID), dim3(RT_BVH_BLOCK), 0, stream, S, B, C_BQA + d, C_BQA_NEXT + d);
         });
     }
     void prep(const RenderArgs& A, int d, uint32_t n) { timed(RT_K_PREP, [&] { hipLaunchKernelGGL(k_prep, dim3(grid_d(d, n, RT_GRID_PREP)), dim3(RT_BLOCK), 0, stream, S, A, B, d, n); }); }
@@ -595,7 +601,7 @@ size_t carve_batch(Batch& B, char* base, uint32_t P, int levels, uint32_t nl, ui
     B.bq_b = (q4*)take(sizeof(q4) * (size_t)B.bq_cap);
     B.bq_c = (q4*)take(sizeof(q4) * (size_t)B.cq_cap);
     B.bq_roots = (uint32_t*)take(4ull * RT_DEFER_ROOTS * (size_t)B.bq_cap);
-    B.bq_spill = (uint32_t*)take(4ull * (RT_STACK_DEPTH - RT_LDS_STACK) * RT_MAX_GRID * RT_BLOCK);
+    B.bq_spill = (uint32_t*)take(4ull * (RT_STACK_DEPTH - RT_LDS_STACK) * RT_BVH_GRID * RT_BVH_BLOCK);
     return off;
 }
 } // namespace
