@@ -18,18 +18,12 @@
 #include <string>
 #include <vector>
 
-#include "rt_pipeline.hpp"
+#include "rt_kernels.hpp"
 #include "rt_lbvh.hpp"
 #include "rt_scene.hpp"
 
 using namespace rt;
 
-#ifndef RT_BLOCK
-#define RT_BLOCK 256
-#endif
-#ifndef RT_MAX_GRID
-#define RT_MAX_GRID (256 * 8)   // persistent k_bvh, and the default of the grid-stride kernels
-#endif
 // Grid-stride kernels: a grid slightly above what is resident at once ends in a thin second round of blocks, so
 // a kernel launches either what fits in one round (even work per item: k_prep, k_shade at 7 waves/SIMD hold 1792
 // blocks; 1536 measured best) or many rounds of short blocks that the dispatcher balances (uneven work per item:
@@ -54,28 +48,6 @@ using namespace rt;
 constexpr uint32_t rt_max_u32(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
 // ---- kernels -------------------------------------------------------------------------------------
-// cls 0 closest-hit queries, 1 shadow rays, 2 AO rays.  The ray counts (cls 1, 2) are always kept;
-// the traversal counters only in the STATS variants.
-template <bool STATS>
-__device__ inline void flush_counters(const Counters& c, unsigned long long* stats, int cls)
-{
-    if (cls != 0) {
-        uint32_t r = c.rays;
-        for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off);
-        if ((threadIdx.x & 63) == 0 && r) atomicAdd(&stats[cls == 1 ? ST_SHADOW : ST_AO], (unsigned long long)r);
-    }
-    if (!STATS) return;
-    uint32_t n = c.nodes, t = c.tris, g = c.gates;
-    for (int off = 32; off > 0; off >>= 1) {
-        n += __shfl_xor(n, off); t += __shfl_xor(t, off); g += __shfl_xor(g, off);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&stats[ST_NODES + cls], (unsigned long long)n);
-        atomicAdd(&stats[ST_TRIS + cls], (unsigned long long)t);
-        atomicAdd(&stats[ST_GATES + cls], (unsigned long long)g);
-    }
-}
-
 // The first RT_LDS_GATES nodes of the gate array (all of it for the reference's scenes) are staged
 // in LDS once per block: the walk reads one 48-byte node per step, every lane of a wave mostly the
 // same one, and an LDS broadcast read has a fraction of the L1/L2 round trip's latency.
@@ -157,222 +129,6 @@ __global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B
     }
     close_cursor(qc, B.bq_roots, (uint32_t)REF_NONE, B.bq_cap);
     flush_counters<STATS>(cnt, B.stats, 2);
-}
-
-// Compacted triangle-BVH traversal (the dominant kernel).  Persistent waves with three ideas:
-//  * refill: a lane that finishes its ray fetches the next one from the queue (the wave takes
-//    RT_BVH_CHUNK consecutive items with one atomic; a single hot counter word serves only ~90
-//    returning atomics per microsecond: MI355X_MICROARCH.md row 'dequeue'), so short rays do not
-//    idle their lanes until the longest ray of the wave is done;
-//  * decoupled node / triangle work: leaves met during the descent are parked in a small per-lane
-//    LDS queue instead of being tested on the spot, and every iteration the wave votes (ballot +
-//    popcount) for ONE kind of step — a 64-byte node fetch + two box tests, or one 48-byte
-//    triangle fetch + exact test — whichever more lanes are ready for;
-//  * the exact Moller-Trumbore test is evaluated branch-free (same operations, same order as
-//    tri_t(); only the early returns are folded into one predicate).
-// Results are identical to bvh_item()/bvh_drain() (rt_pipeline.hpp / rt_core.hpp), which the CPU
-// emulation runs: the closest hit does not depend on visiting order (ties resolved by rank).
-#ifndef RT_BVH_CHUNK
-#define RT_BVH_CHUNK 512
-#endif
-#ifndef RT_REFILL_IDLE
-#define RT_REFILL_IDLE 40    // refill once this many lanes hold no ray
-#endif
-#ifndef RT_PEND
-#define RT_PEND 2            // parked leaves per lane
-#endif
-#ifndef RT_NODE_REPS
-#define RT_NODE_REPS 4       // steps of one kind per vote (see the vote below)
-#endif
-#ifndef RT_TRI_REPS
-#define RT_TRI_REPS 6
-#endif
-#ifndef RT_REP_NUM
-#define RT_REP_NUM 1         // repeat while RT_REP_NUM/RT_REP_DEN of the voters are ready again
-#define RT_REP_DEN 4
-#endif
-#ifndef RT_LDS_STACK
-#define RT_LDS_STACK 12      // stack entries per lane kept in LDS; deeper ones spill to global memory (rare)
-#endif
-
-#ifndef RT_BVH_BLOCK
-#define RT_BVH_BLOCK RT_BLOCK   // threads per block and blocks of the persistent kernel
-#endif
-#ifndef RT_BVH_GRID
-#define RT_BVH_GRID RT_MAX_GRID
-#endif
-template <bool AO, bool STATS>
-__global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int counter, int next_counter)
-{
-    __shared__ uint32_t s_stack[RT_LDS_STACK * RT_BVH_BLOCK];
-    __shared__ uint32_t s_pend[RT_PEND * RT_BVH_BLOCK];
-    // volatile: keeps the (rare) global spill accesses from being merged with the LDS ones into
-    // generic-pointer (flat) instructions, which wait on both memory counters
-    volatile uint32_t* const spill = B.bq_spill + (size_t)blockIdx.x * RT_BVH_BLOCK + threadIdx.x;
-    const size_t spill_stride = (size_t)RT_BVH_GRID * RT_BVH_BLOCK;
-    auto push = [&](uint32_t& sp_, uint32_t x) {
-        if (sp_ < RT_LDS_STACK) s_stack[sp_ * RT_BVH_BLOCK + threadIdx.x] = x;
-        else if (sp_ < RT_STACK_DEPTH) spill[(size_t)(sp_ - RT_LDS_STACK) * spill_stride] = x;
-        else return;
-        ++sp_;
-    };
-    auto pop = [&](uint32_t& sp_) -> uint32_t {
-        --sp_;
-        uint32_t x = s_stack[(sp_ < RT_LDS_STACK ? sp_ : RT_LDS_STACK - 1) * RT_BVH_BLOCK + threadIdx.x];
-        if (sp_ >= RT_LDS_STACK) x = spill[(size_t)(sp_ - RT_LDS_STACK) * spill_stride];
-        return x;
-    };
-    uint32_t n = B.counters[counter];
-    if (n > (AO ? B.bq_cap : B.cq_cap)) n = AO ? B.bq_cap : B.cq_cap;
-    // a wave takes at least 64 items, so waves beyond ceil(n/64) have nothing to fetch: they leave before touching
-    // the queue counter (the launches of the deeper levels of a small frame hold a few hundred rays for 8192 waves)
-    if ((uint64_t)(blockIdx.x * (RT_BVH_BLOCK / 64) + (threadIdx.x >> 6)) * 64u >= n) return;
-    uint32_t* next = &B.counters[next_counter];
-    uint32_t* pend = s_pend + threadIdx.x;
-    Counters cnt{0, 0, 0, 0};
-    const uint32_t lane = threadIdx.x & 63u;
-    f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
-    RayCull rc = {};
-    Hit best = {};
-    uint32_t sp = 0, cur = REF_NONE, dst = 0, npend = 0, tri_next = 0, tri_left = 0;
-    bool active = false, exhausted = false;
-    uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform
-    uint32_t nrays = 0;
-    uint32_t dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // STATS: wave-uniform diagnostics (see ST_DIAG)
-    for (;;) {
-        // ---- retire finished rays -------------------------------------------------------------
-        if (active && cur == REF_NONE && npend == 0 && tri_left == 0) {
-            if (AO) B.ao_t[dst] = best.t;
-            else { const q4 r = {best.t, u2f(best.prim), best.u, best.v}; B.hit[dst] = r; }
-            active = false;
-        }
-        // ---- refill ---------------------------------------------------------------------------
-        const unsigned long long idle = __ballot(!active);
-        const uint32_t nidle = (uint32_t)__popcll(idle);
-        if (!exhausted && (nidle >= RT_REFILL_IDLE)) {
-            if (chunk_next >= chunk_end) {
-                // guided self-scheduling: full chunks while plenty of items remain, smaller ones near the
-                // end of the queue so the launch does not end with a few waves holding hundreds of rays
-                const uint32_t rem = chunk_end < n ? n - chunk_end : 0u;
-                uint32_t take = (rem >> 14) << 6;
-                take = take < 64u ? 64u : (take > RT_BVH_CHUNK ? (uint32_t)RT_BVH_CHUNK : take);
-                if (chunk_end == 0) take = RT_BVH_CHUNK;   // first grab: position unknown
-                uint32_t b0 = 0;
-                if (lane == 0) b0 = atomicAdd(next, take);
-                b0 = __shfl(b0, 0);
-                chunk_next = b0; chunk_end = b0 + take < n ? b0 + take : n;
-                if (b0 >= n) { exhausted = true; chunk_next = chunk_end = 0; }
-            }
-            const uint32_t base = chunk_next, lim = chunk_end;
-            chunk_next = base + nidle < lim ? base + nidle : lim;
-            if (STATS && AO) { dg[6]++; dg[7] += chunk_next - base; }
-            if (!active) {
-                const uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                if (idx < lim) {   // items at or beyond the chunk end are left for the next refill
-                    const q4 a = B.bq_a[idx], b = B.bq_b[idx];
-                    const uint32_t root0 = B.bq_roots[idx];   // REF_NONE marks a hole
-                    o = xyz(a); d = xyz(b);
-                    const uint32_t nroots = (f2u(b.w) >> 29) + 1u;
-                    dst = f2u(b.w) & 0x1FFFFFFFu;
-                    best.t = a.w; best.prim = H_MISS; best.rank = 0; best.u = 0; best.v = 0;
-                    if (!AO) { const q4 c = B.bq_c[idx]; best.prim = f2u(c.x); best.rank = f2u(c.y); best.u = c.z; best.v = c.w; }
-                    rc = make_cull(S, o, d);
-                    sp = 0; npend = 0; tri_left = 0;
-                    if (root0 != REF_NONE) {
-                        push(sp, root0);
-                        for (uint32_t k = 1; k < nroots; ++k) push(sp, B.bq_roots[(size_t)k * B.bq_cap + idx]);   // rare: one Mesh is the rule
-                    }
-                    if (sp > 0) { cur = pop(sp); active = true; if (STATS) nrays++; }   // a slot without roots is a hole
-                }
-            }
-        }
-        // ---- vote for the kind of step ------------------------------------------------------------
-        const bool can_node = active && cur != REF_NONE && (!(cur & REF_LEAF) || npend < RT_PEND);
-        const bool can_tri = active && (tri_left > 0 || npend > 0);
-        const uint32_t n_node = (uint32_t)__popcll(__ballot(can_node));
-        const uint32_t n_tri = (uint32_t)__popcll(__ballot(can_tri));
-        if (n_node == 0 && n_tri == 0) {
-            if (__ballot(active) == 0ull && (exhausted || n == 0)) break;
-            continue;   // only finished rays (retired at the top) or an empty refill: go round again
-        }
-        // The winner of the vote is repeated (up to RT_*_REPS steps) while RT_REP_NUM/RT_REP_DEN of its voters
-        // are ready again: the retire / refill / vote code above is a third of an iteration.
-        if (STATS && AO) { dg[4]++; dg[5] += (uint32_t)__popcll(__ballot(active)); }
-        if (n_node > n_tri) {
-            bool cn = can_node;
-            for (int rep = 0;; ++rep) {
-                if (STATS && AO) { dg[0]++; dg[1] += (uint32_t)__popcll(__ballot(cn)); }
-                if (cn) {
-                    uint32_t c0 = REF_NONE, c1 = REF_NONE;
-                    if (!(cur & REF_LEAF)) {
-                        const q4* np = S.nodes + (size_t)cur * 2;
-                        const q4 n0 = np[0], n1 = np[1];
-                        if (STATS) cnt.nodes++;
-                        uint32_t r0, r1;
-                        float t0, t1;
-                        bool h0, h1;
-                        node_test(rc, n0, n1, best.t, h0, h1, t0, t1, r0, r1);
-                        const bool swap = h0 && h1 && t1 < t0;
-                        c0 = h0 ? r0 : (uint32_t)REF_NONE; c1 = h1 ? r1 : (uint32_t)REF_NONE;
-                        if (swap) { const uint32_t x = c0; c0 = c1; c1 = x; }
-                    } else {
-                        c0 = cur;   // a leaf that arrived as a root or waited for room
-                    }
-                    // leaves are parked for the triangle steps; inner nodes continue the descent
-                    if (c0 != REF_NONE && (c0 & REF_LEAF) && npend < RT_PEND) { pend[(npend++) * RT_BVH_BLOCK] = c0; c0 = REF_NONE; }
-                    if (c1 != REF_NONE && (c1 & REF_LEAF) && npend < RT_PEND) { pend[(npend++) * RT_BVH_BLOCK] = c1; c1 = REF_NONE; }
-                    if (c0 == REF_NONE) { c0 = c1; c1 = REF_NONE; }
-                    if (c1 != REF_NONE) push(sp, c1);
-                    cur = c0;
-                    while (cur == REF_NONE && sp > 0) {   // pop; leaves that come off the stack are parked right away
-                        const uint32_t x = pop(sp);
-                        if ((x & REF_LEAF) && npend < RT_PEND) pend[(npend++) * RT_BVH_BLOCK] = x;
-                        else cur = x;
-                    }
-                }
-                if (rep == RT_NODE_REPS - 1) break;
-                cn = active && cur != REF_NONE && (!(cur & REF_LEAF) || npend < RT_PEND);
-                if ((uint32_t)__popcll(__ballot(cn)) * RT_REP_DEN < n_node * RT_REP_NUM) break;
-            }
-        } else {
-            bool ct = can_tri;
-            for (int rep = 0;; ++rep) {
-                if (STATS && AO) { dg[2]++; dg[3] += (uint32_t)__popcll(__ballot(ct)); }
-                if (ct) {
-                    if (tri_left == 0) {
-                        const uint32_t ref = pend[(--npend) * RT_BVH_BLOCK];
-                        tri_next = ref & 0x0FFFFFFFu; tri_left = ((ref >> 28) & 7u) + 1u;
-                    }
-                    const q4* T = S.tris + (size_t)tri_next * 3;
-                    const q4 a = T[0], b = T[1], e = T[2];
-                    if (STATS) cnt.tris++;
-                    // Triangle::intersectRay (reference main.cpp:713-739), branch-free
-                    const f3 v0v1 = xyz(b), v0v2 = xyz(e);
-                    const f3 pvec = cross(d, v0v2);
-                    const float det = dot(v0v1, pvec);
-                    const float invDet = 1.0f / det;
-                    const f3 tvec = o - xyz(a);
-                    const float u = dot(tvec, pvec) * invDet;
-                    const f3 qvec = cross(tvec, v0v1);
-                    const float v = dot(d, qvec) * invDet;
-                    const float t = dot(v0v2, qvec) * invDet;
-                    const bool ok = !(det < 0.000001f) && !(u < 0 || u > 1) && !(v < 0 || u + v > 1);
-                    const uint32_t rank = f2u(e.w);
-                    if (ok && closer(t, rank, best)) { best.t = t; best.prim = H_TRI | tri_next; best.u = u; best.v = v; best.rank = rank; }
-                    tri_next++; tri_left--;
-                }
-                if (rep == RT_TRI_REPS - 1) break;
-                ct = active && (tri_left > 0 || npend > 0);
-                if ((uint32_t)__popcll(__ballot(ct)) * RT_REP_DEN < n_tri * RT_REP_NUM) break;
-            }
-        }
-    }
-    flush_counters<STATS>(cnt, B.stats, AO ? 2 : 0);
-    if (STATS) {
-        for (int off = 32; off > 0; off >>= 1) nrays += __shfl_xor(nrays, off);
-        if (lane == 0) atomicAdd(&B.stats[ST_BVHRAYS + (AO ? 2 : 0)], (unsigned long long)nrays);
-        if (AO && lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&B.stats[ST_DIAG + k], (unsigned long long)dg[k]);
-    }
 }
 
 __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
@@ -528,16 +284,14 @@ struct GpuBackend {
     void bvh_trace(const RenderArgs& A, int d)
     {
         timed(RT_K_TRACE_BVH, [&] {
-            if (stats) hipLaunchKernelGGL((k_bvh<false, true>), dim3(RT_BVH_GRID), dim3(RT_BVH_BLOCK), 0, stream, S, B, C_BQ + d, C_BQ_NEXT + d);
-            else hipLaunchKernelGGL((k_bvh<false, false>), dim3(RT_BVH_GRID), dim3(RT_BVH_BLOCK), 0, stream, S, B, C_BQ + d, C_BQ_NEXT + d);
+            launch_k_bvh(false, stats, stream, S, B, C_BQ + d, C_BQ_NEXT + d);
         });
     }
     void bvh_ao(const RenderArgs& A, int d)
     {
         if (S.ambient.occlusion_samples <= 0) return;
         timed(RT_K_AO_BVH, [&] {
-            if (stats) hipLaunchKernelGGL((k_bvh<true, true>), dim3(RT_BVH_GRID), dim3(RT_BVH_BLOCK), 0, stream, S, B, C_BQA + d, C_BQA_NEXT + d);
-            else hipLaunchKernelGGL((k_bvh<true, false>), dim3(RT_BVH_GRID), dim3(RT_BVH_BLOCK), 0, stream, S, B, C_BQA + d, C_BQA_NEXT + d);
+            launch_k_bvh(true, stats, stream, S, B, C_BQA + d, C_BQA_NEXT + d);
         });
     }
     void prep(const RenderArgs& A, int d, uint32_t n) { timed(RT_K_PREP, [&] { hipLaunchKernelGGL(k_prep, dim3(grid_d(d, n, RT_GRID_PREP)), dim3(RT_BLOCK), 0, stream, S, A, B, d, n); }); }

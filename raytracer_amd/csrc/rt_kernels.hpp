@@ -1,0 +1,52 @@
+// rt_kernels.hpp — what the two kernel translation units share: rt_gpu.hip (pipeline kernels, launch geometry, C ABI)
+// and rt_bvh.hip (the persistent triangle-BVH kernel, compiled with its own instruction-scheduling strategy).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rt_pipeline.hpp"
+
+#ifndef RT_BLOCK
+#define RT_BLOCK 256
+#endif
+#ifndef RT_MAX_GRID
+#define RT_MAX_GRID (256 * 8)   // persistent k_bvh, and the default of the grid-stride kernels
+#endif
+#ifndef RT_LDS_STACK
+#define RT_LDS_STACK 12      // k_bvh: stack entries per lane kept in LDS; deeper ones spill to global memory (rare)
+#endif
+#ifndef RT_BVH_BLOCK
+#define RT_BVH_BLOCK RT_BLOCK   // threads per block and blocks of the persistent kernel (swept 64-512 / 1024-8192: no effect)
+#endif
+#ifndef RT_BVH_GRID
+#define RT_BVH_GRID RT_MAX_GRID
+#endif
+
+namespace rt {
+
+// cls 0 closest-hit queries, 1 shadow rays, 2 AO rays.  The ray counts (cls 1, 2) are always kept;
+// the traversal counters only in the STATS variants.
+template <bool STATS>
+__device__ inline void flush_counters(const Counters& c, unsigned long long* stats, int cls)
+{
+    if (cls != 0) {
+        uint32_t r = c.rays;
+        for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off);
+        if ((threadIdx.x & 63) == 0 && r) atomicAdd(&stats[cls == 1 ? ST_SHADOW : ST_AO], (unsigned long long)r);
+    }
+    if (!STATS) return;
+    uint32_t n = c.nodes, t = c.tris, g = c.gates;
+    for (int off = 32; off > 0; off >>= 1) {
+        n += __shfl_xor(n, off); t += __shfl_xor(t, off); g += __shfl_xor(g, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&stats[ST_NODES + cls], (unsigned long long)n);
+        atomicAdd(&stats[ST_TRIS + cls], (unsigned long long)t);
+        atomicAdd(&stats[ST_GATES + cls], (unsigned long long)g);
+    }
+}
+
+
+// rt_bvh.hip: k_bvh<ao, stats> on RT_BVH_GRID x RT_BVH_BLOCK over the queue counted by counters[counter]
+void launch_k_bvh(bool ao, bool stats, hipStream_t stream, const DScene& S, const Batch& B, int counter, int next_counter);
+
+} // namespace rt
