@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
             active = false;
         }
         // ---- refill ---------------------------------------------------------------------------
-        const unsigned long long idle = __ballot(!active);
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(!active);
         const uint32_t nidle = (uint32_t)__popcll(idle);
         if (!exhausted && (nidle >= RT_REFILL_IDLE)) {
             if (chunk_next >= chunk_end) {
@@ -127,19 +127,19 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
         // ---- vote for the kind of step ------------------------------------------------------------
         const bool can_node = active && cur != REF_NONE && (!(cur & REF_LEAF) || npend < RT_PEND);
         const bool can_tri = active && (tri_left > 0 || npend > 0);
-        const uint32_t n_node = (uint32_t)__popcll(__ballot(can_node));
-        const uint32_t n_tri = (uint32_t)__popcll(__ballot(can_tri));
+        const uint32_t n_node = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(can_node));
+        const uint32_t n_tri = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(can_tri));
         if (n_node == 0 && n_tri == 0) {
-            if (__ballot(active) == 0ull && (exhausted || n == 0)) break;
+            if (__builtin_amdgcn_ballot_w64(active) == 0ull && (exhausted || n == 0)) break;
             continue;   // only finished rays (retired at the top) or an empty refill: go round again
         }
         // The winner of the vote is repeated (up to RT_*_REPS steps) while RT_REP_NUM/RT_REP_DEN of its voters
         // are ready again: the retire / refill / vote code above is a third of an iteration.
-        if (STATS && AO) { dg[4]++; dg[5] += (uint32_t)__popcll(__ballot(active)); }
+        if (STATS && AO) { dg[4]++; dg[5] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(active)); }
         if (n_node > n_tri) {
             bool cn = can_node;
             for (int rep = 0;; ++rep) {
-                if (STATS && AO) { dg[0]++; dg[1] += (uint32_t)__popcll(__ballot(cn)); }
+                if (STATS && AO) { dg[0]++; dg[1] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(cn)); }
                 if (cn) {
                     uint32_t c0 = REF_NONE, c1 = REF_NONE;
                     if (!(cur & REF_LEAF)) {
@@ -170,12 +170,12 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
                 }
                 if (rep == RT_NODE_REPS - 1) break;
                 cn = active && cur != REF_NONE && (!(cur & REF_LEAF) || npend < RT_PEND);
-                if ((uint32_t)__popcll(__ballot(cn)) * RT_REP_DEN < n_node * RT_REP_NUM) break;
+                if ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(cn)) * RT_REP_DEN < n_node * RT_REP_NUM) break;
             }
         } else {
             bool ct = can_tri;
             for (int rep = 0;; ++rep) {
-                if (STATS && AO) { dg[2]++; dg[3] += (uint32_t)__popcll(__ballot(ct)); }
+                if (STATS && AO) { dg[2]++; dg[3] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ct)); }
                 if (ct) {
                     if (tri_left == 0) {
                         const uint32_t ref = pend[(--npend) * RT_BVH_BLOCK];
@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
                 }
                 if (rep == RT_TRI_REPS - 1) break;
                 ct = active && (tri_left > 0 || npend > 0);
-                if ((uint32_t)__popcll(__ballot(ct)) * RT_REP_DEN < n_tri * RT_REP_NUM) break;
+                if ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ct)) * RT_REP_DEN < n_tri * RT_REP_NUM) break;
             }
         }
     }

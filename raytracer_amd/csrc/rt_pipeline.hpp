@@ -102,7 +102,7 @@ RT_FN PathPix path_of(const RenderArgs& A, uint32_t p)
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ inline uint32_t queue_slot(uint32_t* counter)
 {
-    unsigned long long mask = __ballot(1);
+    unsigned long long mask = __builtin_amdgcn_ballot_w64(1);
     uint32_t lane = __lane_id();
     uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
     uint32_t base = 0;
@@ -168,7 +168,7 @@ template <uint32_t CHUNK>
 RT_FN uint32_t chunk_append(uint32_t* counter, bool want, QCursor& qc, uint32_t* holes, uint32_t hole_value, uint32_t cap)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned long long mask = __ballot(want);
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
     const uint32_t nw = (uint32_t)__popcll(mask);
     if (nw == 0) return 0xFFFFFFFFu;
     const uint32_t lane = __lane_id();
