@@ -157,11 +157,18 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
                         c0 = cur;   // a leaf that arrived as a root or waited for room
                     }
                     // leaves are parked for the triangle steps; inner nodes continue the descent
-                    if (c0 != REF_NONE && (c0 & REF_LEAF) && npend < RT_PEND) { pend[(npend++) * RT_BVH_BLOCK] = c0; c0 = REF_NONE; }
-                    if (c1 != REF_NONE && (c1 & REF_LEAF) && npend < RT_PEND) { pend[(npend++) * RT_BVH_BLOCK] = c1; c1 = REF_NONE; }
-                    if (c0 == REF_NONE) { c0 = c1; c1 = REF_NONE; }
-                    if (c1 != REF_NONE) push(sp, c1);
-                    cur = c0;
+                    // straight-line selects instead of nested conditionals: 5 VALU instructions fewer per step
+                    // (REF_NONE is positive as an int: "negative" = a leaf that was hit)
+                    const bool p0 = (int32_t)c0 < 0 && npend < RT_PEND;
+                    if (p0) pend[npend * RT_BVH_BLOCK] = c0;
+                    npend += p0 ? 1u : 0u;
+                    const bool p1 = (int32_t)c1 < 0 && npend < RT_PEND;
+                    if (p1) pend[npend * RT_BVH_BLOCK] = c1;
+                    npend += p1 ? 1u : 0u;
+                    const uint32_t a = p0 ? (uint32_t)REF_NONE : c0, b = p1 ? (uint32_t)REF_NONE : c1;
+                    const bool an = a == REF_NONE;
+                    cur = an ? b : a;
+                    if (!an && b != REF_NONE) push(sp, b);
                     while (cur == REF_NONE && sp > 0) {   // pop; leaves that come off the stack are parked right away
                         const uint32_t x = pop(sp);
                         if ((x & REF_LEAF) && npend < RT_PEND) pend[(npend++) * RT_BVH_BLOCK] = x;
@@ -196,7 +203,9 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
                     const float t = dot(v0v2, qvec) * invDet;
                     const bool ok = !(det < 0.000001f) && !(u < 0 || u > 1) && !(v < 0 || u + v > 1);
                     const uint32_t rank = f2u(e.w);
-                    if (ok && closer(t, rank, best)) { best.t = t; best.prim = H_TRI | tri_next; best.u = u; best.v = v; best.rank = rank; }
+                    if (AO) {   // only the distance leaves this kernel: the reference's first-wins rule on equal t cannot change it
+                        if (ok && t < best.t) best.t = t;
+                    } else if (ok && closer(t, rank, best)) { best.t = t; best.prim = H_TRI | tri_next; best.u = u; best.v = v; best.rank = rank; }
                     tri_next++; tri_left--;
                 }
                 if (rep == RT_TRI_REPS - 1) break;
