@@ -664,7 +664,7 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
     const uint32_t nl = S.num_lights ? S.num_lights : 1;
     const uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
     // Paths per batch.  Default: as many as the 29-bit ray ids of the BVH queue items allow (P * n^2 < 2^29), at
-    // most 32 Mi, in equal batches (4K, 16 spp, 4x4 AO: 4 batches of 510 tiles, ~45 GB of the 288 GB) — every
+    // most 32 Mi, in equal batches (4K, 16 spp, 4x4 AO: 4 batches of 510 tiles, ~52 GB of the 288 GB) — every
     // launch of a persistent kernel ends in a drain tail, so fewer, larger batches are faster (8 -> 4: +1 %).
     uint64_t want = p->batch_paths ? p->batch_paths : (32u << 20);
     if (!p->batch_paths) {
