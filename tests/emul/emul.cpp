@@ -220,4 +220,7 @@ int emul_gate_check(uint32_t n, uint32_t seed, double* out)
     return 0;
 }
 
+// chunk size a launch takes for its queue appends (rt_pipeline.hpp)
+uint32_t emul_queue_chunk(unsigned long long appends, uint32_t waves, uint32_t largest) { return queue_chunk(appends, waves, largest); }
+
 } // extern "C"

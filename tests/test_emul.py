@@ -138,3 +138,24 @@ def test_random_scenes(emul, port, seed):
     assert np.array_equal(prim, want.primid)
     assert util.bits_equal(t, want.t)
     assert util.lsb_diff(rgb, want.rgb).max() <= 1
+
+
+def test_queue_chunk_properties(emul):
+    """queue_chunk(): a power of two in [64, largest], never more than a quarter of a wave's expected appends
+    (above the floor of 64), monotone in the number of appends, and the largest chunk for the bench's launches."""
+    import ctypes as C
+    f = emul.lib.emul_queue_chunk
+    f.argtypes = [C.c_ulonglong, C.c_uint32, C.c_uint32]
+    f.restype = C.c_uint32
+    for largest in (512, 1024):
+        for waves in (1, 4, 6144, 8192, 131072):
+            last = 0
+            for appends in (0, 1, 63, 64, 1000, 10**5, 10**6, 10**7, 10**8, 534_773_760, 2**32):
+                c = f(appends, waves, largest)
+                assert 64 <= c <= largest and c & (c - 1) == 0
+                assert c == 64 or c * 4 * waves <= appends
+                assert c >= last
+                last = c
+    assert f(33_423_360, 6144, 512) == 512          # k_prep, config 3: 1536 blocks of 4 waves
+    assert f(534_773_760, 131072, 1024) == 512      # k_ao, config 3: 32768 blocks
+    assert f(2_000_000, 8192, 1024) == 64           # a small frame
