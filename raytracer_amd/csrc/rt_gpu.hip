@@ -28,7 +28,7 @@ using namespace rt;
 // a kernel launches either what fits in one round (even work per item: k_prep, k_shade at 7 waves/SIMD hold 1792
 // blocks; 1536 measured best) or many rounds of short blocks that the dispatcher balances (uneven work per item:
 // the gate walks).  Measured on config 3 (ms per frame): k_ao 55.3 / 52.3 / 50.0 / 48.8 / 46.3 / 51.0 at 2048 /
-// 4096 / 8192 / 16384 / 32768 / 65536 blocks; k_shadow 11.6 / 11.2 / 11.0 at 2048 / 4096 / 8192; k_prep 5.3 -> 4.8
+// 4096 / 8192 / 16384 / 32768 / 65536 blocks; k_shadow 11.6 / 11.2 / 11.0 at 2048 / 4096 / 8192 (256-thread blocks); k_prep 5.3 -> 4.8
 // and k_shade 4.7 -> 4.0 at 1536; k_trace best at 2048.
 #ifndef RT_GRID_TRACE
 #define RT_GRID_TRACE RT_MAX_GRID
@@ -37,7 +37,7 @@ using namespace rt;
 #define RT_GRID_PREP 1536
 #endif
 #ifndef RT_GRID_SHADOW
-#define RT_GRID_SHADOW 8192
+#define RT_GRID_SHADOW 16384   // blocks of RT_SHADOW_BLOCK threads
 #endif
 #ifndef RT_GRID_AO
 #define RT_GRID_AO 32768
@@ -55,7 +55,7 @@ constexpr uint32_t rt_max_u32(uint32_t a, uint32_t b) { return a > b ? a : b; }
 __device__ inline void stage_gates(DScene& S, GateNode* s_gates)
 {
     const uint32_t nf = S.num_gates < RT_LDS_GATES ? S.num_gates : RT_LDS_GATES;
-    for (uint32_t k = threadIdx.x; k < nf * 3u; k += RT_BLOCK) ((q4*)s_gates)[k] = ((const q4*)S.gates)[k];
+    for (uint32_t k = threadIdx.x; k < nf * 3u; k += blockDim.x) ((q4*)s_gates)[k] = ((const q4*)S.gates)[k];
     __syncthreads();
     S.gates_fast = s_gates; S.num_gates_fast = nf;
 }
@@ -96,16 +96,20 @@ __global__ void __launch_bounds__(RT_BLOCK) k_prep(DScene S, RenderArgs A, Batch
     close_cursor(qsh, B.sh_queue, 0xFFFFFFFFu, B.sh_cap);
 }
 
+// k_shadow traverses inline, lane by lane: half-size blocks (2 waves) even out its uneven rays a little better (11.1 -> 10.3 ms)
+#ifndef RT_SHADOW_BLOCK
+#define RT_SHADOW_BLOCK 128
+#endif
 template <bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene S, RenderArgs A, Batch B, int depth)
+__global__ void __launch_bounds__(RT_SHADOW_BLOCK) k_shadow(DScene S, RenderArgs A, Batch B, int depth)
 {
-    __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_BLOCK];
+    __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_SHADOW_BLOCK];
     __shared__ GateNode s_gates[RT_LDS_GATES];
     stage_gates(S, s_gates);
     const uint32_t n = B.counters[C_SH + depth] < B.sh_cap ? B.counters[C_SH + depth] : B.sh_cap;
-    Stack st{s_stack + threadIdx.x, RT_BLOCK};
+    Stack st{s_stack + threadIdx.x, RT_SHADOW_BLOCK};
     Counters cnt{0, 0, 0, 0};
-    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK)
+    for (uint32_t i = blockIdx.x * RT_SHADOW_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_SHADOW_BLOCK)
         shadow_item<STATS>(S, A, B, depth, i, st, cnt);
     flush_counters<STATS>(cnt, B.stats, 1);
 }
@@ -298,10 +302,10 @@ struct GpuBackend {
     void shadow(const RenderArgs& A, int d)
     {
         if (S.num_lights == 0) return;
-        const uint32_t g = grid_many((uint64_t)B.P * S.num_lights, d == 0 ? RT_GRID_SHADOW : RT_MAX_GRID);   // the queue cannot hold more than this; deeper levels are usually short
+        const uint32_t g = grid_many((uint64_t)B.P * S.num_lights * (RT_BLOCK / RT_SHADOW_BLOCK), d == 0 ? RT_GRID_SHADOW : RT_MAX_GRID);   // the queue cannot hold more than this; deeper levels are usually short
         timed(RT_K_SHADOW, [&] {
-            if (stats) hipLaunchKernelGGL(k_shadow<true>, dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d);
-            else hipLaunchKernelGGL(k_shadow<false>, dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d);
+            if (stats) hipLaunchKernelGGL(k_shadow<true>, dim3(g), dim3(RT_SHADOW_BLOCK), 0, stream, S, A, B, d);
+            else hipLaunchKernelGGL(k_shadow<false>, dim3(g), dim3(RT_SHADOW_BLOCK), 0, stream, S, A, B, d);
         });
     }
     void ao(const RenderArgs& A, int d, uint32_t n)
