@@ -88,8 +88,9 @@ def main():
 
     def step(flags=0, stats=None):
         params.flags = flags
-        # stream=None: the library's own stream, and the call returns when the frame is complete
-        r.render_device(world.camera, params, out.data_ptr(), None, None, stats, None)
+        # on torch's current stream: ordered behind the allocation fills above and, with N > 1, behind the
+        # previous step's gather / unpack, which read `slab` (include/rt_amd.h, stream contract)
+        r.render_device(world.camera, params, out.data_ptr(), None, None, stats, torch.cuda.current_stream().cuda_stream)
         if distributed:   # the one exchange step: slabs -> rank 0 over RCCL, scattered into the frame there
             if args.backend == "nccl":
                 rdist.gather_frame(slab, params, rank, world_size, unpack, gather_list=gather_list)
@@ -153,9 +154,17 @@ def main():
             except Exception:
                 traffic = None
         ao_rays = float(st_count.rays_ao)
+        launch_s = (k_ms / max(1.0, k_launches)) * 1e-3
+        # `achieved` / `frac` are ALGORITHMIC bytes (cache hits count) over the launch time, as SURVEY 8d defines them;
+        # `traffic` is what the HBM counters saw per launch (profiles/traffic.json, separate rocprofv3 --pmc passes) and
+        # `traffic_gbs` / `traffic_frac` the HBM rate that corresponds to.  The kernel's working set sits in L2 / MALL,
+        # so it is the VALU issue rate, not HBM, that limits it: `limiter` says so.
         roofline = {
             "bound": "hbm", "kernel": "k_bvh<AO>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_gbs": round(traffic / launch_s / 1e9, 1) if traffic and launch_s > 0 else None,
+            "traffic_frac": round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic and launch_s > 0 else None,
+            "limiter": "valu-issue (working set served by L2/MALL; see profiles/*_pmc.csv)",
             "bytes_per_ray": round(b_ray, 1), "nodes_per_ray": round(V, 2), "tris_per_ray": round(T, 2),
             "rays_per_launch": round(units / max(1.0, k_launches), 1), "avg_launch_ms": round(k_ms / max(1.0, k_launches), 4),
             "mrays_per_s_in_kernel": round(units / (k_ms * 1e-3) / 1e6, 1) if k_ms > 0 else None,
@@ -187,7 +196,11 @@ def cpu_baseline(world, flat, args):
     same scene at 1 spp (the reference algorithm scans every triangle of a mesh per ray)."""
     from oracle import bindings
     from raytracer_amd import capi
-    nthreads = min(16, os.cpu_count() or 1)
+    # all the cores this process may use: the box's CPU share (exported as OMP_NUM_THREADS there; os.cpu_count()
+    # shows the whole machine), else the affinity mask
+    host_cpus = os.cpu_count() or 1
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or len(os.sched_getaffinity(0))
+    nthreads = max(1, min(share, host_cpus))
     if bindings.RefOracle.available():
         orc, kind = bindings.RefOracle(), "reference"
     else:
@@ -198,7 +211,8 @@ def cpu_baseline(world, flat, args):
     p.x0, p.x1 = args.width // 2 - c // 2, args.width // 2 - c // 2 + c
     p.y0, p.y1 = args.height // 2 - c // 2, args.height // 2 - c // 2 + c
     res = orc.render(flat, world.camera, p, rng_mode=1, nthreads=nthreads, ids=False)
-    return {"value": round(res.rays / res.seconds / 1e6, 4), "unit": "Mrays/s", "cores": nthreads, "kind": kind,
+    return {"value": round(res.rays / res.seconds / 1e6, 4), "unit": "Mrays/s", "cores": nthreads, "threads": nthreads,
+            "host_cpus": host_cpus, "kind": kind,
             "sample": f"{c}x{c} px centre crop of the same frame at 1 spp (jitter + 4x4 AO on), {res.rays} rays in {res.seconds:.1f} s"}
 
 

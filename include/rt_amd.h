@@ -216,7 +216,18 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* p,
 /* Same, writing to device memory and returning as soon as the work is queued on `stream`
  * (a hipStream_t passed as void*; NULL = the context's own stream, in which case the call
  * also waits).  With tile_world > 1, d_rgb is this rank's compact tile slab
- * [rt_owned_tiles()][RT_TILE*RT_TILE][3] instead of a full frame. */
+ * [rt_owned_tiles()][RT_TILE*RT_TILE][3] instead of a full frame.
+ *
+ * Stream contract of every entry point that takes a `stream` (rt_render_device, rt_unpack_tiles,
+ * rt_quantize_rgb8, rt_encode_bmp24):
+ *   - stream != NULL: the work is queued on that stream, behind whatever the caller queued there
+ *     (fills, copies, collectives that produce or consume the buffers); the call does not wait.
+ *   - stream == NULL: the work runs on the context's own stream, ordered after everything the
+ *     caller had queued on the legacy default (null) stream when the call was made, and the call
+ *     returns when it is complete.  Work the caller queued on any OTHER stream is NOT ordered
+ *     against it: pass that stream (e.g. torch.cuda.current_stream().cuda_stream) instead.
+ *   - one context carries one render at a time: a render on another stream waits (on the device)
+ *     for the previous one, since they share the context's ray queues and counters. */
 int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* p,
                      float* d_rgb, uint32_t* d_primid, float* d_t, rt_stats* stats, void* stream);
 

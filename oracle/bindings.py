@@ -108,6 +108,17 @@ class RefOracle(_Base):
         L.ref_quantize.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.ref_bvh_dump.argtypes = [C.POINTER(capi.rt_scene_desc), C.POINTER(capi.rt_params), C.c_char_p,
                                    C.c_uint32, C.c_void_p, C.c_int]
+        L.ref_save_bmp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
+
+    def save_bmp_bytes(self, rgb):
+        """The bytes the reference's saveToFile (main.cpp:1837-1857, stbi_write_bmp) writes for rgb[H,W,3]."""
+        rgb = np.ascontiguousarray(rgb, np.float32)
+        h, w = rgb.shape[:2]
+        path = os.path.join(self._tmp, "ref_save.bmp")
+        if self.lib.ref_save_bmp(rgb.ctypes.data, w, h, path.encode()) != 0:
+            raise RuntimeError("ref_save_bmp failed")
+        with open(path, "rb") as f:
+            return f.read()
 
     def bvh_dump(self, flat, params, which=0, cap=4096):
         out = np.zeros((cap, 9), np.float32)

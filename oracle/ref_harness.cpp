@@ -569,6 +569,16 @@ void ref_quantize(const float* rgb, size_t n, uint8_t* out)
     for (size_t i = 0; i < n; ++i) out[i] = static_cast<unsigned char>(rgb[i] * 255);
 }
 
+// The reference's own saveToFile (main.cpp:1837-1857: truncating conversion + stbi_write_bmp) on a caller's
+// float image, so that the device encoder (rt_encode_bmp24) is checked against bytes the reference wrote.
+int ref_save_bmp(const float* rgb, int width, int height, const char* path)
+{
+    std::vector<Colour> image((size_t)width * height);
+    for (size_t i = 0; i < image.size(); ++i) image[i] = Colour{rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]};
+    saveToFile(std::string(path), (std::size_t)width, (std::size_t)height, image);
+    return 0;
+}
+
 // BVHAccel hierarchy dump for a desc's bvh #which: per node {leaf, left, right, min[3], max[3]}
 int ref_bvh_dump(const rt_scene_desc* d, const rt_params* p, const char* tmpdir, uint32_t which, float* out, int cap_nodes)
 {

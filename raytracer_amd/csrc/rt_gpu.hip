@@ -188,8 +188,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bmp24(const float* rgb, uint8_t* f
         o[1] = (uint8_t)(int)(rgb[i * 3 + 1] * 255.0f);
         o[0] = (uint8_t)(int)(rgb[i * 3 + 2] * 255.0f);
         if (x == (uint32_t)width - 1u) for (uint32_t k = (uint32_t)width * 3u; k < row_bytes; ++k) o[3 + (k - (uint32_t)width * 3u)] = 0;
-        if (i < 54) file[i] = hdr.b[i];
     }
+    // the 54 header bytes: threads 0..53 of block 0, whatever the number of pixels (a 4x4 image has 16)
+    if (blockIdx.x == 0 && threadIdx.x < 54) file[threadIdx.x] = hdr.b[threadIdx.x];
 }
 
 // ---- context / scene objects ------------------------------------------------------------------------
@@ -205,6 +206,11 @@ struct rt_ctx {
     float* d_rgb = nullptr; uint32_t* d_prim = nullptr; float* d_t = nullptr; size_t out_pixels = 0;
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    // Stream ordering.  ev_done: end of the last piece of work that used the context's shared buffers (batch
+    // buffers, counters, statistics), on whatever stream it ran: the next one waits for it, so one context carries
+    // one render at a time even when callers alternate streams.  ev_null: see order_after_null_stream().
+    hipEvent_t ev_done = nullptr, ev_null = nullptr;
+    bool done_recorded = false;
 };
 
 struct rt_scene {
@@ -228,6 +234,30 @@ static std::string g_init_error;
             return RT_ERR_HIP;                                                                   \
         }                                                                                        \
     } while (0)
+
+// A call with stream == NULL runs on the context's own stream.  That stream is created without
+// hipStreamNonBlocking, so it is already ordered with the legacy default (null) stream; the explicit event makes
+// the contract independent of that flag: everything the caller queued on the null stream before the call
+// (e.g. a framework's fill or copy of a buffer handed to us) completes before our kernels touch the buffers.
+// Work the caller queued on OTHER streams is not covered: pass that stream instead of NULL.
+static int order_after_null_stream(rt_ctx* ctx)
+{
+    HIPCHECK(ctx, hipEventRecord(ctx->ev_null, nullptr));
+    HIPCHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_null, 0));
+    return RT_OK;
+}
+// `st` is about to use the context's shared buffers: wait for the previous user; mark_done() after queueing.
+static int order_after_previous_work(rt_ctx* ctx, hipStream_t st)
+{
+    if (ctx->done_recorded) HIPCHECK(ctx, hipStreamWaitEvent(st, ctx->ev_done, 0));
+    return RT_OK;
+}
+static int mark_done(rt_ctx* ctx, hipStream_t st)
+{
+    HIPCHECK(ctx, hipEventRecord(ctx->ev_done, st));
+    ctx->done_recorded = true;
+    return RT_OK;
+}
 
 static inline uint32_t grid_for(uint64_t n, uint32_t cap = RT_MAX_GRID)
 {
@@ -396,7 +426,10 @@ int rt_init(int device, rt_ctx** out)
     rt_ctx* c = new (std::nothrow) rt_ctx();
     if (!c) return RT_ERR_NOMEM;
     c->device = device;
-    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+    // a blocking stream (no hipStreamNonBlocking): ordered with the legacy default stream in both directions
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamDefault)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_null, hipEventDisableTiming)) != hipSuccess ||
         (e = hipMalloc((void**)&c->d_stats, sizeof(unsigned long long) * ST_TOTAL)) != hipSuccess ||
         (e = hipMalloc((void**)&c->d_counters, sizeof(uint32_t) * C_TOTAL)) != hipSuccess ||
         (e = hipEventCreate(&c->ev_begin)) != hipSuccess || (e = hipEventCreate(&c->ev_end)) != hipSuccess) {
@@ -416,6 +449,8 @@ int rt_shutdown(rt_ctx* c)
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    if (c->ev_null) (void)hipEventDestroy(c->ev_null);
     (void)hipFree(c->batch_mem); (void)hipFree(c->d_stats); (void)hipFree(c->d_counters);
     (void)hipFree(c->d_rgb); (void)hipFree(c->d_prim); (void)hipFree(c->d_t);
     (void)hipStreamDestroy(c->stream);
@@ -692,6 +727,7 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
         const size_t need = carve_batch(B, nullptr, P, levels_alloc, nl, n2);
         if (need <= ctx->batch_bytes) break;
         HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->done_recorded) HIPCHECK(ctx, hipEventSynchronize(ctx->ev_done));   // a render still running on a caller's stream
         if (ctx->batch_mem) HIPCHECK(ctx, hipFree(ctx->batch_mem));
         ctx->batch_mem = nullptr; ctx->batch_bytes = 0;
         const hipError_t e = hipMalloc(&ctx->batch_mem, need);
@@ -708,6 +744,10 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
     B.stats = ctx->d_stats;
 
     GpuBackend be{ctx, S, B, stream, (p->flags & RT_FLAG_STATS) != 0, (p->flags & RT_FLAG_TIMING) != 0, levels_alloc};
+    {   // the batch buffers, counters and statistics are the context's: wait for their previous user (any stream)
+        const int rc = order_after_previous_work(ctx, stream);
+        if (rc) return rc;
+    }
     HIPCHECK(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * ST_TOTAL, stream));
     HIPCHECK(ctx, hipEventRecord(ctx->ev_begin, stream));
     uint32_t batches = 0;
@@ -716,6 +756,10 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
         batches = (owned + tiles_per_batch - 1) / tiles_per_batch;
     }
     HIPCHECK(ctx, hipEventRecord(ctx->ev_end, stream));
+    {
+        const int rc = mark_done(ctx, stream);
+        if (rc) return rc;
+    }
     if (be.err != hipSuccess) { ctx->error = std::string("rt_render: launch failed: ") + hipGetErrorString(be.err); return RT_ERR_HIP; }
     if (!wait && !stats) return RT_OK;
     HIPCHECK(ctx, hipStreamSynchronize(stream));
@@ -763,6 +807,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* p, floa
     if (rc) return rc;
     HIPCHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (!stream) { rc = order_after_null_stream(ctx); if (rc) return rc; }
     return render_locked(s, cam, p, d_rgb, d_primid, d_t, stats, st, p->tile_world > 1, stream == nullptr);
 }
 
@@ -822,6 +867,7 @@ int rt_unpack_tiles(rt_ctx* ctx, const float* d_slab, const rt_params* p, int ra
     uint32_t tx, ty;
     tile_grid(p, tx, ty);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (!stream) { const int rc = order_after_null_stream(ctx); if (rc) return rc; }
     hipLaunchKernelGGL(k_unpack, dim3(grid_for((uint64_t)owned * RT_TILE * RT_TILE)), dim3(RT_BLOCK), 0, st,
                        d_slab, d_frame, p->width, p->x0, p->y0, p->x1, p->y1, tx, ty, rank, world, owned);
     HIPCHECK(ctx, hipGetLastError());
@@ -835,6 +881,7 @@ int rt_quantize_rgb8(rt_ctx* ctx, const float* d_rgb, size_t num_pixels, uint8_t
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (!stream) { const int rc = order_after_null_stream(ctx); if (rc) return rc; }
     if (num_pixels) hipLaunchKernelGGL(k_quantize, dim3(grid_for(num_pixels * 3)), dim3(RT_BLOCK), 0, st, d_rgb, d_rgb8, num_pixels * 3);
     HIPCHECK(ctx, hipGetLastError());
     if (!stream) HIPCHECK(ctx, hipStreamSynchronize(st));
@@ -864,6 +911,7 @@ int rt_encode_bmp24(rt_ctx* ctx, const float* d_rgb, int width, int height, uint
     put32(14, 40); put32(18, (uint32_t)width); put32(22, (uint32_t)height);
     h.b[26] = 1; h.b[28] = 24;
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (!stream) { const int rc = order_after_null_stream(ctx); if (rc) return rc; }
     hipLaunchKernelGGL(k_bmp24, dim3(grid_for((size_t)width * height)), dim3(RT_BLOCK), 0, st, d_rgb, d_file, width, height, row, h);
     HIPCHECK(ctx, hipGetLastError());
     if (!stream) HIPCHECK(ctx, hipStreamSynchronize(st));

@@ -12,6 +12,10 @@ Also writes known-answer vectors of single reference functions (kat.npz) and the
 decode of models/teapot/default.png (teapot_default_rgba.npz).
 Usage:  python tests/golden/make_golden.py        (needs /root/reference; run in the build container)
         python tests/golden/make_golden.py converged    only the stochastic fixture below (about 4 minutes)
+        python tests/golden/make_golden.py converged_random   the same for the reference's Random sampler
+        python tests/golden/make_golden.py bmp          only bmp_savetofile.npz (the reference's saveToFile bytes)
+        python tests/golden/make_golden.py only NAME... only these scene fixtures
+        python tests/golden/make_golden.py cpp_host     only cpp_default_160x120.npz (fixture of the C++ drop-in test)
 
 converged_default_libc_rand.npz (SURVEY.md 8c "stochastic parity protocol"): the mean of 32 independent
 runs of the unmodified reference (rng_mode 0: libc rand() and its own Sampler with std::random_device,
@@ -49,18 +53,94 @@ def converged(ref, runs=32):
     print("converged: single-run PSNR against the mean of the others %.2f dB (min %.2f)" % (np.mean(loo), np.min(loo)))
 
 
+def converged_random(ref, runs=32):
+    """The same protocol for the reference's own Random sampler (main.cpp:1019-1035: std::mt19937 seeded by
+    std::random_device, not reproducible): mean of `runs` runs of the unmodified reference, Random(16,83), 4x4 AO."""
+    from raytracer_amd import scenes, scene as S
+    w = scenes.default_scene(72, 72, sampler=S.Random(16, 83), ao_samples=4)
+    flat, p = w.flatten(), w.params()
+    imgs = np.stack([ref.render(flat, w.camera, p, rng_mode=0, nthreads=8, ids=False).rgb.astype(np.float64)
+                     for _ in range(runs)])
+    total = imgs.sum(axis=0)
+    loo = [util.psnr(imgs[k], (total - imgs[k]) / (runs - 1)) for k in range(runs)]
+    np.savez_compressed(os.path.join(HERE, "converged_default_random.npz"), rgb=(total / runs).astype(np.float32),
+                        runs=np.int32(runs), single_run_psnr=np.array(loo, np.float64),
+                        params=np.frombuffer(bytes(p), dtype=np.uint8))
+    print("converged (Random sampler): single-run PSNR against the mean of the others %.2f dB (min %.2f)" % (np.mean(loo), np.min(loo)))
+
+
+def bmp_inputs():
+    """Float images for the saveToFile fixtures: widths 200 and 101 (row padding 0 and 1 bytes), a 4x4 image
+    (fewer pixels than header bytes) and a 3x5 one (3 bytes of padding).  Values in [0,1] with the exact
+    multiples of 1/255 and their neighbours mixed in (truncation edges)."""
+    rng = np.random.default_rng(2024)
+    out = {}
+    for name, (w, h) in (("200x24", (200, 24)), ("101x47", (101, 47)), ("4x4", (4, 4)), ("3x5", (3, 5))):
+        img = rng.random((h, w, 3), dtype=np.float32)
+        k = rng.integers(0, 256, (h, w, 3)).astype(np.float32) / np.float32(255)
+        pick = rng.integers(0, 4, (h, w, 3))
+        img = np.where(pick == 0, k, img)
+        img = np.where(pick == 1, np.nextafter(k, np.float32(0), dtype=np.float32), img)
+        img = np.where(pick == 2, np.nextafter(k, np.float32(2), dtype=np.float32), img).astype(np.float32)
+        img = np.clip(img, 0.0, 1.0)
+        img.reshape(-1)[:3] = (0.0, 1.0, 0.5)
+        out[name] = np.ascontiguousarray(img)
+    return out
+
+
+def bmp(ref):
+    """saveToFile fixtures: the float inputs and the bytes the REFERENCE's saveToFile (main.cpp:1837-1857,
+    stbi_write_bmp) wrote for them."""
+    fx = {}
+    for name, img in bmp_inputs().items():
+        fx["rgb_" + name] = img
+        fx["bmp_" + name] = np.frombuffer(ref.save_bmp_bytes(img), np.uint8)
+        print("bmp", name, len(fx["bmp_" + name]), "bytes")
+    np.savez_compressed(os.path.join(HERE, "bmp_savetofile.npz"), **fx)
+
+
+def cpp_host(ref):
+    """What examples/default_scene.cpp (the reference's main() scene script on the C++ drop-in host) must write
+    for `default_scene <models> out.bmp 160 120`: the REAL reference's render of the same scene (rng_mode 1,
+    seed 1 = World::seed's default) as 8-bit RGB, and the BMP its saveToFile writes for it."""
+    from raytracer_amd import scenes, scene as S
+    w = scenes.default_scene(160, 120, sampler=S.Jitter(4, 83), ao_samples=4)
+    p = w.params(seed=1)
+    r = ref.render(w.flatten(), w.camera, p, rng_mode=1, nthreads=8, ids=False)
+    np.savez_compressed(os.path.join(HERE, "cpp_default_160x120.npz"), rgb8=util.quantize(r.rgb),
+                        bmp=np.frombuffer(ref.save_bmp_bytes(r.rgb), np.uint8),
+                        params=np.frombuffer(bytes(p), dtype=np.uint8))
+    print("cpp_host fixture", r.rgb.shape, "rays", r.rays)
+
+
 def main():
     ref = RefOracle()
+    if sys.argv[1:] == ["cpp_host"]:
+        cpp_host(ref)
+        return
     if sys.argv[1:] == ["converged"]:
         converged(ref)
         return
+    if sys.argv[1:] == ["converged_random"]:
+        converged_random(ref)
+        return
+    if sys.argv[1:] == ["bmp"]:
+        bmp(ref)
+        return
+    only = set(sys.argv[2:]) if sys.argv[1:2] == ["only"] else None   # `only name ...`: just these scene fixtures
     for name, world, params in util.small_scenes():
+        if only is not None and name not in only:
+            continue
         flat = world.flatten()
         r = ref.render(flat, world.camera, params, rng_mode=1, nthreads=8)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), rgb=r.rgb, primid=r.primid, t=r.t, normal=r.normal,
                             uv=r.uv, rays=np.uint64(r.rays),
                             params=np.frombuffer(bytes(params), dtype=np.uint8))
         print(name, r.rgb.shape, "rays", r.rays)
+    if only is not None:
+        return
+    bmp(ref)
+    cpp_host(ref)
 
     # known-answer vectors of single functions
     rng = np.random.default_rng(1234)

@@ -77,7 +77,83 @@ def small_scenes():
     out.append(("config3_textured_mesh", w, w.params(seed=11)))
     w = scenes.config5_scene(64, 36, spp=1, instances=9, mesh_nu=12, mesh_nv=8)
     out.append(("config5_instanced", w, w.params(seed=5)))
+    # rows a14 / a16: Matte::shade (main.cpp:1143-1165) and Directional (main.cpp:1307-1345), deterministic
+    w = matte_directional_scene(72, 54)
+    out.append(("matte_directional", w, w.params(seed=4)))
+    # row a3: RT_SAMPLER_RANDOM.  The reference's Random::generateSamples (main.cpp:1019-1035) draws from a
+    # std::mt19937 seeded by std::random_device: not reproducible, so this bit-level case pins the GPU to the
+    # oracle/harness statement of it (uniform points from the counter hash) and PARITY WITH THE REFERENCE'S OWN
+    # GENERATOR IS UNPINNED at the bit level; tests/test_gpu_parity.py compares it statistically with the
+    # unmodified reference (converged_default_random.npz).
+    w = scenes.default_scene(64, 48, sampler=S.Random(4, 83), ao_samples=2)
+    out.append(("default_random4", w, w.params(seed=13)))
+    # row a17 / SURVEY Q13: a non-square texture (the reference strides rows by mHeight)
+    w = nonsquare_texture_scene(64, 48)
+    out.append(("nonsquare_texture", w, w.params(seed=6)))
     return out
+
+
+def matte_directional_scene(width=72, height=54):
+    """Matte spheres / plane / free triangle lit by a Directional light (plus a weak PointLight: Matte does not
+    normalise wi, main.cpp:1155-1160, so a point light multiplies by the distance), a Specular sphere whose
+    shadow rays start at the Directional light's source point P + 1e6 * dir, AO on (Matte uses the ambient term)."""
+    from raytracer_amd import scenes, scene as S
+    w = S.World()
+    w.width, w.height = width, height
+    w.sampler = S.Jitter(4, 11)
+    m1 = S.Matte(); m1.setDiffuseColour((0.9, 0.4, 0.2)); m1.setDiffuseReflection(0.8); m1.setAmbientReflection(0.4)
+    m2 = S.Matte(); m2.setDiffuseColour((0.3, 0.6, 0.9)); m2.setDiffuseReflection(0.6); m2.setAmbientReflection(0.7)
+    m3 = S.Matte(); m3.setDiffuseColour((0.7, 0.7, 0.7)); m3.setDiffuseReflection(0.5); m3.setAmbientReflection(0.5)
+    spec = S.Specular(); spec.setDiffuseColour((0.2, 0.8, 0.3))
+    mirror = S.Mirror(); mirror.setAmbientColour((0.7, 0.7, 0.7)); mirror.setAmbientReflection(0.1)
+    floor = S.Plane((0, -100, 0), (0, 1, 0)).setMaterial(m3)
+    back = S.Plane((0, 0, -400), (0, 0, 1)).setMaterial(spec)
+    s1 = S.Sphere((-120, -20, -50), 80).setMaterial(m1)
+    s2 = S.Sphere((90, -40, 30), 60).setMaterial(m2)
+    s3 = S.Sphere((0, 90, -150), 70).setMaterial(spec)
+    s4 = S.Sphere((190, 40, -120), 50).setMaterial(mirror)
+    tri = S.Triangle((-260, -100, -250), (-60, -100, -330), (-180, 160, -300), (0, 0), (1, 0), (0.5, 1)).setMaterial(m2)
+    bvh = S.BVHAccel()
+    for s in (s1, s2, s3, s4, tri):
+        bvh.addShape(s)
+    bvh.generateBVH()
+    w.scene = [floor, back, bvh]
+    w.ambient = S.Ambient(2, 600.0)
+    w.ambient.setColour((1, 1, 1)); w.ambient.scaleRadiance(0.6)
+    sun = S.Directional((0.4, 1.0, 0.5)); sun.setColour((1.0, 0.95, 0.8)); sun.scaleRadiance(0.7)
+    lamp = S.PointLight((-300, 400, 300)); lamp.setColour((0.6, 0.7, 1.0)); lamp.scaleRadiance(0.0004)
+    w.lights = [sun, lamp]
+    w.camera = S.Camera((40, 120, 520), (0, 0, -60), (0, 1, 0), 60.0 * height / 48.0)
+    return w
+
+
+def nonsquare_texture_scene(width=64, height=48):
+    """A 96x40 noise texture on a mesh and on a free triangle.  width > height keeps the reference's
+    (x + mHeight*y)*4 texel offset (main.cpp:173-188) inside the image, so its result is defined."""
+    import numpy as np
+    from raytracer_amd import scenes, scene as S
+    rng = np.random.default_rng(77)
+    rgba = rng.integers(0, 256, (40, 96, 4)).astype(np.uint8)
+    rgba[..., 3] = 255
+    rgba[::2, :, 0] //= 2     # some row structure, so that a wrong stride shows
+    tex = S.ImageTexture(rgba)
+    assert tex.width == 96 and tex.height == 40
+    mt = S.Textured(tex); mt.setAmbientReflection(0.8)
+    w = S.World()
+    w.width, w.height = width, height
+    w.sampler = S.Jitter(4, 5)
+    spec = S.Specular(); spec.setDiffuseColour((0.8, 0.8, 0.8))
+    obj = scenes.torus_objmesh(mt, 20, 10, R=70.0, r=30.0, centre=(0.0, 0.0, 0.0), tile=(3, 2))
+    mm = S.MultiMesh(obj, "", (-40, 10, 0))
+    tri = S.Triangle((60, -90, -80), (260, -90, 40), (150, 170, -20), (0.02, 0.03), (0.97, 0.1), (0.5, 0.98)).setMaterial(mt)
+    floor = S.Plane((0, -100, 0), (0, 1, 0)).setMaterial(spec)
+    w.scene = [floor, mm, tri]
+    w.ambient = S.Ambient(0)
+    w.ambient.setColour((1, 1, 1)); w.ambient.scaleRadiance(0.9)
+    light = S.PointLight((100, 500, 600)); light.setColour((1, 1, 1)); light.scaleRadiance(0.6)
+    w.lights = [light]
+    w.camera = S.Camera((60, 120, 420), (40, 20, 0), (0, 1, 0), 55.0 * height / 48.0)
+    return w
 
 
 def mesh_tunnel_scene(width=64, height=48, meshes=14):
