@@ -125,6 +125,29 @@ def exported_symbols():
     return list(_EXPORTS)
 
 
+def _share_the_process_hip_runtime():
+    """One HIP/HSA runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7) and load it by file name; librt_amd.so needs `libamdhip64.so.7`.  If torch's copy is loaded
+    first, ours binds to it by SONAME and all is well; if ours pulls in /opt/rocm's copy first, a later `import torch`
+    loads a SECOND runtime stack whose initialisation fails ("No HIP GPUs are available").  So when torch is
+    installed and no HIP runtime is mapped yet, map torch's copy first.  Nothing is imported or initialised here."""
+    try:
+        with open("/proc/self/maps") as f:
+            if "libamdhip64" in f.read():
+                return
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            cand = os.path.join(libdir, name)
+            if os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except (OSError, ImportError, ValueError):
+        pass
+
+
 def load_library(path=None):
     """dlopen librt_amd.so.  Raises (no fallback) when the HIP extension has not been built."""
     global _lib
@@ -135,6 +158,7 @@ def load_library(path=None):
         raise RuntimeError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the render path.")
+    _share_the_process_hip_runtime()
     lib = C.CDLL(path)
     vp = C.c_void_p
     lib.rt_init.argtypes = [C.c_int, C.POINTER(vp)]
