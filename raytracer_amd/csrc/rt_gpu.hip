@@ -193,10 +193,24 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bmp24(const float* rgb, uint8_t* f
     if (blockIdx.x == 0 && threadIdx.x < 54) file[threadIdx.x] = hdr.b[threadIdx.x];
 }
 
+// ---- rt_render_device_noalloc's scratch ---------------------------------------------------------------
+// The allocation-free entry point (include/rt_amd.h) keeps the wavefront pipeline's per-batch buffers (ray records,
+// hit records, the path / shadow / BVH work queues, AO distances, per-level shading terms, k_bvh's spill stacks, the
+// queue counters and the ray statistics) in this file-scope device array instead of hipMalloc'ed memory.  Every GPU
+// the library runs on holds its own copy at its own address for the life of the process.  In host code the name
+// `scratch` is only a handle for hipGetSymbolAddress: rt_init resolves it once per device, with that device
+// current, and host code uses the resolved pointer (g_scratch_ptr[device]) everywhere — kernel arguments,
+// hipMemsetAsync — never the array's name.  RT_NOALLOC_SCRATCH_BYTES: include/rt_amd.h.
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+#define RT_MAX_DEVICES 64
+static unsigned char* g_scratch_ptr[RT_MAX_DEVICES];   // per device, set by rt_init under g_scratch_mu
+static std::mutex g_scratch_mu;
+
 // ---- context / scene objects ------------------------------------------------------------------------
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    unsigned char* scratch_ptr = nullptr;   // this device's copy of `scratch` (resolved address), RT_NOALLOC_SCRATCH_BYTES long
     std::string error;
     std::mutex mu;
     // cached per-render buffers
@@ -423,9 +437,24 @@ int rt_init(int device, rt_ctx** out)
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { g_init_error = hipGetErrorString(e); return RT_ERR_HIP; }
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { g_init_error = std::string("rt_init: kernels are built for gfx950 only, device is ") + prop.gcnArchName; return RT_ERR_HIP; }
     if ((e = hipSetDevice(device)) != hipSuccess) { g_init_error = hipGetErrorString(e); return RT_ERR_HIP; }
+    if (device >= RT_MAX_DEVICES) { g_init_error = "rt_init: device index beyond RT_MAX_DEVICES"; return RT_ERR_UNSUPPORTED; }
+    unsigned char* scratch_dev = nullptr;
+    {   // once per device, with that device current: the address of this GPU's copy of `scratch`
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        if (!g_scratch_ptr[device]) {
+            void* sp = nullptr;
+            if ((e = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch))) != hipSuccess || !sp) {
+                g_init_error = std::string("rt_init: hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
+                return RT_ERR_HIP;
+            }
+            g_scratch_ptr[device] = static_cast<unsigned char*>(sp);
+        }
+        scratch_dev = g_scratch_ptr[device];
+    }
     rt_ctx* c = new (std::nothrow) rt_ctx();
     if (!c) return RT_ERR_NOMEM;
     c->device = device;
+    c->scratch_ptr = scratch_dev;
     // a blocking stream (no hipStreamNonBlocking): ordered with the legacy default stream in both directions
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamDefault)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming)) != hipSuccess ||
@@ -681,8 +710,11 @@ int rt_owned_tiles(const rt_params* p, int rank, int world, uint32_t* out)
     return RT_OK;
 }
 
+// fixed_mem != nullptr (rt_render_device_noalloc): every device buffer of the render is carved out of
+// [fixed_mem, fixed_mem + fixed_bytes) and nothing is allocated, freed, created or read back.
 static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, float* d_rgb, uint32_t* d_prim,
-                         float* d_t, rt_stats* stats, hipStream_t stream, bool slab, bool wait)
+                         float* d_t, rt_stats* stats, hipStream_t stream, bool slab, bool wait,
+                         unsigned char* fixed_mem = nullptr, size_t fixed_bytes = 0)
 {
     rt_ctx* ctx = s->ctx;
     const DScene& S = s->dev;
@@ -715,7 +747,38 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
     if (tiles_per_batch > owned && owned > 0) tiles_per_batch = owned;
     Batch B{};
     uint32_t P = 0;
-    for (;;) {
+    // fixed memory: [counters][statistics][batch buffers]
+    const size_t fixed_head = align_up(sizeof(uint32_t) * C_TOTAL, 256) + align_up(sizeof(unsigned long long) * ST_TOTAL, 256);
+    if (fixed_mem) {
+        if (fixed_bytes <= fixed_head) { ctx->error = "rt_render_device_noalloc: scratch smaller than its header"; return RT_ERR_UNSUPPORTED; }
+        const size_t avail = fixed_bytes - fixed_head;
+        for (;;) {
+            if (owned > 0) {   // equal batches
+                const uint32_t nb = (owned + tiles_per_batch - 1) / tiles_per_batch;
+                tiles_per_batch = (owned + nb - 1) / nb;
+            }
+            size_t need = ~(size_t)0;
+            const uint64_t paths = (uint64_t)tiles_per_batch * per_tile;
+            if (paths <= 0x7FFFFFFFull && paths * nl <= 0xFFFFFFFFull && paths * (n2 ? n2 : 1) < (1ull << 29)) {
+                P = (uint32_t)paths;
+                need = carve_batch(B, nullptr, P, levels_alloc, nl, n2);
+            }
+            if (need <= avail) break;
+            if (tiles_per_batch == 1) {
+                char msg[320];
+                std::snprintf(msg, sizeof msg, "rt_render_device_noalloc: one %dx%d tile at %d samples per pixel, %u light(s), %u AO rays per hit and "
+                              "%d shading level(s) needs %zu bytes of queues, the fixed scratch holds %zu (RT_NOALLOC_SCRATCH_BYTES = %llu): "
+                              "lower num_samples or use rt_render_device", RT_TILE, RT_TILE, A.spp, nl, n2, levels_alloc, need + fixed_head, fixed_bytes,
+                              (unsigned long long)RT_NOALLOC_SCRATCH_BYTES);
+                ctx->error = msg;
+                return RT_ERR_UNSUPPORTED;
+            }
+            // need grows linearly with the tiles of a batch (plus a constant): aim below the estimate, then step down
+            const uint64_t guess = need == ~(size_t)0 ? tiles_per_batch / 2 : (uint64_t)((double)tiles_per_batch * (double)avail / (double)need);
+            tiles_per_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(guess, tiles_per_batch - 1));
+        }
+    }
+    for (; !fixed_mem;) {
         if (!p->batch_paths && owned > 0) {   // equal batches
             const uint32_t nb = (owned + tiles_per_batch - 1) / tiles_per_batch;
             tiles_per_batch = (owned + nb - 1) / nb;
@@ -738,24 +801,24 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
             ctx->error = std::string("rt_render: hipMalloc of the batch buffers: ") + hipGetErrorString(e); return RT_ERR_HIP; }
         tiles_per_batch = (tiles_per_batch + 1) / 2;
     }
-    carve_batch(B, (char*)ctx->batch_mem, P, levels_alloc, nl, n2);
+    carve_batch(B, fixed_mem ? (char*)fixed_mem + fixed_head : (char*)ctx->batch_mem, P, levels_alloc, nl, n2);
     if (S.debug & 8u) { B.bq_cap = std::min<uint32_t>(B.bq_cap, 3000u); B.cq_cap = std::min<uint32_t>(B.cq_cap, 3000u); }   // test switch: a BVH queue that overflows (inline traversal path)
-    B.counters = ctx->d_counters;
-    B.stats = ctx->d_stats;
+    B.counters = fixed_mem ? (uint32_t*)fixed_mem : ctx->d_counters;
+    B.stats = fixed_mem ? (unsigned long long*)(fixed_mem + align_up(sizeof(uint32_t) * C_TOTAL, 256)) : ctx->d_stats;
 
     GpuBackend be{ctx, S, B, stream, (p->flags & RT_FLAG_STATS) != 0, (p->flags & RT_FLAG_TIMING) != 0, levels_alloc};
     {   // the batch buffers, counters and statistics are the context's: wait for their previous user (any stream)
         const int rc = order_after_previous_work(ctx, stream);
         if (rc) return rc;
     }
-    HIPCHECK(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * ST_TOTAL, stream));
-    HIPCHECK(ctx, hipEventRecord(ctx->ev_begin, stream));
+    HIPCHECK(ctx, hipMemsetAsync(B.stats, 0, sizeof(unsigned long long) * ST_TOTAL, stream));   // the array keeps the last call's contents
+    if (!fixed_mem) HIPCHECK(ctx, hipEventRecord(ctx->ev_begin, stream));
     uint32_t batches = 0;
     if (owned > 0 && p->x1 > p->x0 && p->y1 > p->y0) {
         render_frame(be, A, owned, tiles_per_batch, bounces);
         batches = (owned + tiles_per_batch - 1) / tiles_per_batch;
     }
-    HIPCHECK(ctx, hipEventRecord(ctx->ev_end, stream));
+    if (!fixed_mem) HIPCHECK(ctx, hipEventRecord(ctx->ev_end, stream));
     {
         const int rc = mark_done(ctx, stream);
         if (rc) return rc;
@@ -809,6 +872,29 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* p, floa
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     if (!stream) { rc = order_after_null_stream(ctx); if (rc) return rc; }
     return render_locked(s, cam, p, d_rgb, d_primid, d_t, stats, st, p->tile_world > 1, stream == nullptr);
+}
+
+int rt_render_device_noalloc(rt_scene* s, const rt_camera* cam, const rt_params* p, float* d_rgb, uint32_t* d_primid,
+                             float* d_t, void* stream)
+{
+    if (!s || !cam || !p || !d_rgb) return RT_ERR_INVALID;
+    rt_ctx* ctx = s->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!s->committed) { ctx->error = "rt_render: scene not committed"; return RT_ERR_STATE; }
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    if (p->flags & (RT_FLAG_STATS | RT_FLAG_TIMING)) {   // statistics are read back and timing creates events: both allocate
+        ctx->error = "rt_render_device_noalloc: RT_FLAG_STATS / RT_FLAG_TIMING are not available here (use rt_render_device)";
+        return RT_ERR_UNSUPPORTED;
+    }
+    if (!ctx->scratch_ptr) { ctx->error = "rt_render_device_noalloc: scratch address was not resolved at rt_init"; return RT_ERR_STATE; }
+    HIPCHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (!stream) { rc = order_after_null_stream(ctx); if (rc) return rc; }
+    rc = render_locked(s, cam, p, d_rgb, d_primid, d_t, nullptr, st, p->tile_world > 1, false, ctx->scratch_ptr, (size_t)RT_NOALLOC_SCRATCH_BYTES);
+    if (rc) return rc;
+    if (!stream) HIPCHECK(ctx, hipStreamSynchronize(st));
+    return RT_OK;
 }
 
 int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* p, float* rgb, uint32_t* primid, float* t, rt_stats* stats)

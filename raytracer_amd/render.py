@@ -92,6 +92,12 @@ class Renderer:
                                        C.byref(stats) if stats is not None else None, stream)
         self._check(rc, "rt_render_device")
 
+    def render_device_noalloc(self, camera, params, d_rgb, d_prim=None, d_t=None, stream=None):
+        """rt_render_device_noalloc: the same render out of the library's fixed device scratch, no allocation."""
+        cam = camera.to_c() if hasattr(camera, "to_c") else camera
+        rc = self.lib.rt_render_device_noalloc(self.scene, C.byref(cam), C.byref(params), d_rgb, d_prim, d_t, stream)
+        self._check(rc, "rt_render_device_noalloc")
+
     def owned_tiles(self, params, rank, world):
         n = C.c_uint32()
         self._check(self.lib.rt_owned_tiles(C.byref(params), rank, world, C.byref(n)), "rt_owned_tiles")
