@@ -240,14 +240,14 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* p,
  * event or stream creation and no read-back.  The frame is rendered in as many batches as that array
  * requires (more, smaller batches than rt_render_device: slower, same pixels, bit for bit).
  *   - limit: one RT_TILE x RT_TILE tile x num_samples paths must fit; with 4x4 ambient occlusion and one
- *     light that is num_samples <= 32 (about 1.6 KB of queues per path + 42 MB of fixed spill stacks).
+ *     light that is num_samples <= 32 (about 1.7 KB of queues per path + 143 MB of fixed spill stacks).
  *     Larger requests fail with RT_ERR_UNSUPPORTED and a message naming the sizes; flags must be 0.
  *   - each GPU holds one such array for the life of the process, shared by every context and call on
  *     that GPU: calls that overlap in time on one GPU (two contexts, or two streams of different
  *     contexts) race on it.  Calls through one context are ordered by the library.
  *   - stream semantics as for rt_render_device. */
 #ifndef RT_NOALLOC_SCRATCH_BYTES
-#define RT_NOALLOC_SCRATCH_BYTES (256ull << 20)
+#define RT_NOALLOC_SCRATCH_BYTES (384ull << 20)
 #endif
 int rt_render_device_noalloc(rt_scene* s, const rt_camera* cam, const rt_params* p,
                              float* d_rgb, uint32_t* d_primid, float* d_t, void* stream);

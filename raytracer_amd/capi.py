@@ -118,7 +118,7 @@ _EXPORTS = [
     "rt_bmp24_bytes", "rt_encode_bmp24", "rt_scene_set_builder", "rt_scene_builder_used",
     "rt_render_device_noalloc",
 ]
-RT_NOALLOC_SCRATCH_BYTES = 256 << 20
+RT_NOALLOC_SCRATCH_BYTES = 384 << 20
 
 _lib = None
 

@@ -13,7 +13,7 @@ using namespace rt;
 //    idle their lanes until the longest ray of the wave is done;
 //  * decoupled node / triangle work: leaves met during the descent are parked in a small per-lane
 //    LDS queue instead of being tested on the spot, and every iteration the wave votes (ballot +
-//    popcount) for ONE kind of step — a 64-byte node fetch + two box tests, or one 48-byte
+//    popcount) for ONE kind of step — a 64-byte four-wide node fetch + four box tests, or one 48-byte
 //    triangle fetch + exact test — whichever more lanes are ready for;
 //  * the exact Moller-Trumbore test is evaluated branch-free (same operations, same order as
 //    tri_t(); only the early returns are folded into one predicate).
@@ -42,22 +42,25 @@ using namespace rt;
 template <bool AO, bool STATS>
 __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int counter, int next_counter)
 {
-    __shared__ uint32_t s_stack[RT_LDS_STACK * RT_BVH_BLOCK];
+    // Per-lane stack of {reference, entry distance of its box}, [entry][lane] (conflict-free).  The distance lets
+    // a pop discard an entry whose box has fallen behind the closest hit found since it was pushed without
+    // fetching the node (18 % of the node fetches of an AO ray otherwise).
+    __shared__ uint2 s_stack[RT_LDS_STACK * RT_BVH_BLOCK];
     __shared__ uint32_t s_pend[RT_PEND * RT_BVH_BLOCK];
     // volatile: keeps the (rare) global spill accesses from being merged with the LDS ones into
     // generic-pointer (flat) instructions, which wait on both memory counters
-    volatile uint32_t* const spill = B.bq_spill + (size_t)blockIdx.x * RT_BVH_BLOCK + threadIdx.x;
+    volatile uint2* const spill = (volatile uint2*)B.bq_spill + (size_t)blockIdx.x * RT_BVH_BLOCK + threadIdx.x;
     const size_t spill_stride = (size_t)RT_BVH_GRID * RT_BVH_BLOCK;
-    auto push = [&](uint32_t& sp_, uint32_t x) {
-        if (sp_ < RT_LDS_STACK) s_stack[sp_ * RT_BVH_BLOCK + threadIdx.x] = x;
-        else if (sp_ < RT_STACK_DEPTH) spill[(size_t)(sp_ - RT_LDS_STACK) * spill_stride] = x;
+    auto push = [&](uint32_t& sp_, uint32_t x, float tn) {
+        if (sp_ < RT_LDS_STACK) s_stack[sp_ * RT_BVH_BLOCK + threadIdx.x] = make_uint2(x, f2u(tn));
+        else if (sp_ < RT_STACK_DEPTH) { spill[(size_t)(sp_ - RT_LDS_STACK) * spill_stride].x = x; spill[(size_t)(sp_ - RT_LDS_STACK) * spill_stride].y = f2u(tn); }
         else return;
         ++sp_;
     };
-    auto pop = [&](uint32_t& sp_) -> uint32_t {
+    auto pop = [&](uint32_t& sp_) -> uint2 {
         --sp_;
-        uint32_t x = s_stack[(sp_ < RT_LDS_STACK ? sp_ : RT_LDS_STACK - 1) * RT_BVH_BLOCK + threadIdx.x];
-        if (sp_ >= RT_LDS_STACK) x = spill[(size_t)(sp_ - RT_LDS_STACK) * spill_stride];
+        uint2 x = s_stack[(sp_ < RT_LDS_STACK ? sp_ : RT_LDS_STACK - 1) * RT_BVH_BLOCK + threadIdx.x];
+        if (sp_ >= RT_LDS_STACK) { x.x = spill[(size_t)(sp_ - RT_LDS_STACK) * spill_stride].x; x.y = spill[(size_t)(sp_ - RT_LDS_STACK) * spill_stride].y; }
         return x;
     };
     uint32_t n = B.counters[counter];
@@ -70,7 +73,7 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
     Counters cnt{0, 0, 0, 0};
     const uint32_t lane = threadIdx.x & 63u;
     f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
-    RayCull rc = {};
+    RayCull4 rc = {};
     Hit best = {};
     uint32_t sp = 0, cur = REF_NONE, dst = 0, npend = 0, tri_next = 0, tri_left = 0;
     bool active = false, exhausted = false;
@@ -80,7 +83,7 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
     for (;;) {
         // ---- retire finished rays -------------------------------------------------------------
         if (active && cur == REF_NONE && npend == 0 && tri_left == 0) {
-            if (AO) B.ao_t[dst] = best.t;
+            if (AO) key_min(&B.ao_key[dst], t_key(best.t));   // the ray's other items and k_ao's own hit meet here
             else { const q4 r = {best.t, u2f(best.prim), best.u, best.v}; B.hit[dst] = r; }
             active = false;
         }
@@ -114,13 +117,13 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
                     dst = f2u(b.w) & 0x1FFFFFFFu;
                     best.t = a.w; best.prim = H_MISS; best.rank = 0; best.u = 0; best.v = 0;
                     if (!AO) { const q4 c = B.bq_c[idx]; best.prim = f2u(c.x); best.rank = f2u(c.y); best.u = c.z; best.v = c.w; }
-                    rc = make_cull(S, o, d);
+                    rc = make_cull4(S, o, d);
                     sp = 0; npend = 0; tri_left = 0;
                     if (root0 != REF_NONE) {
-                        push(sp, root0);
-                        for (uint32_t k = 1; k < nroots; ++k) push(sp, B.bq_roots[(size_t)k * B.bq_cap + idx]);   // rare: one Mesh is the rule
+                        push(sp, root0, -INFINITY);
+                        for (uint32_t k = 1; k < nroots; ++k) push(sp, B.bq_roots[(size_t)k * B.bq_cap + idx], -INFINITY);   // rare: one Mesh is the rule
                     }
-                    if (sp > 0) { cur = pop(sp); active = true; if (STATS) nrays++; }   // a slot without roots is a hole
+                    if (sp > 0) { cur = pop(sp).x; active = true; if (STATS) nrays++; }   // a slot without roots is a hole
                 }
             }
         }
@@ -141,39 +144,35 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
             for (int rep = 0;; ++rep) {
                 if (STATS && AO) { dg[0]++; dg[1] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(cn)); }
                 if (cn) {
-                    uint32_t c0 = REF_NONE, c1 = REF_NONE;
-                    if (!(cur & REF_LEAF)) {
-                        const q4* np = S.nodes + (size_t)cur * 2;
-                        const q4 n0 = np[0], n1 = np[1];
-                        if (STATS) cnt.nodes++;
-                        uint32_t r0, r1;
-                        float t0, t1;
-                        bool h0, h1;
-                        node_test(rc, n0, n1, best.t, h0, h1, t0, t1, r0, r1);
-                        const bool swap = h0 && h1 && t1 < t0;
-                        c0 = h0 ? r0 : (uint32_t)REF_NONE; c1 = h1 ? r1 : (uint32_t)REF_NONE;
-                        if (swap) { const uint32_t x = c0; c0 = c1; c1 = x; }
+                    if (cur & REF_LEAF) {
+                        pend[(npend++) * RT_BVH_BLOCK] = cur;   // a leaf that arrived as a root or waited for room (can_node: there is room now)
                     } else {
-                        c0 = cur;   // a leaf that arrived as a root or waited for room
+                        float t4[4];
+                        uint32_t r4[4];
+                        if (STATS) cnt.nodes++;
+                        // one 64-byte fetch, four box tests, children sorted farthest first (missed ones last)
+                        const uint32_t nh = node_children_desc(S, rc, cur, best.t, t4, r4);
+                        if (sp + 4u <= RT_LDS_STACK) {   // all four pairs at fixed offsets, no predication: what lies beyond sp + nh is never read
+                            uint2* top = s_stack + sp * RT_BVH_BLOCK + threadIdx.x;
+                            top[0 * RT_BVH_BLOCK] = make_uint2(r4[0], f2u(t4[0]));
+                            top[1 * RT_BVH_BLOCK] = make_uint2(r4[1], f2u(t4[1]));
+                            top[2 * RT_BVH_BLOCK] = make_uint2(r4[2], f2u(t4[2]));
+                            top[3 * RT_BVH_BLOCK] = make_uint2(r4[3], f2u(t4[3]));
+                            sp += nh;
+                        } else {
+                            for (uint32_t k = 0; k < 4; ++k) if (k < nh) push(sp, r4[k], t4[k]);
+                        }
                     }
-                    // leaves are parked for the triangle steps; inner nodes continue the descent
-                    // straight-line selects instead of nested conditionals: 5 VALU instructions fewer per step
-                    // (REF_NONE is positive as an int: "negative" = a leaf that was hit)
-                    const bool p0 = (int32_t)c0 < 0 && npend < RT_PEND;
-                    if (p0) pend[npend * RT_BVH_BLOCK] = c0;
-                    npend += p0 ? 1u : 0u;
-                    const bool p1 = (int32_t)c1 < 0 && npend < RT_PEND;
-                    if (p1) pend[npend * RT_BVH_BLOCK] = c1;
-                    npend += p1 ? 1u : 0u;
-                    const uint32_t a = p0 ? (uint32_t)REF_NONE : c0, b = p1 ? (uint32_t)REF_NONE : c1;
-                    const bool an = a == REF_NONE;
-                    cur = an ? b : a;
-                    if (!an && b != REF_NONE) push(sp, b);
-                    while (cur == REF_NONE && sp > 0) {   // pop; leaves that come off the stack are parked right away
-                        const uint32_t x = pop(sp);
-                        if ((x & REF_LEAF) && npend < RT_PEND) pend[(npend++) * RT_BVH_BLOCK] = x;
-                        else cur = x;
+                    // next reference: the nearest child just stored, or what waited below it; entries whose box lies
+                    // behind the closest hit by now are dropped without a fetch, leaves are parked for the triangle steps
+                    uint32_t x = REF_NONE;
+                    while (x == REF_NONE && sp > 0) {
+                        const uint2 y = pop(sp);
+                        if (u2f(y.y) > best.t) continue;
+                        if ((y.x & REF_LEAF) && npend < RT_PEND) pend[(npend++) * RT_BVH_BLOCK] = y.x;
+                        else x = y.x;
                     }
+                    cur = x;
                 }
                 if (rep == RT_NODE_REPS - 1) break;
                 cn = active && cur != REF_NONE && (!(cur & REF_LEAF) || npend < RT_PEND);

@@ -81,7 +81,7 @@ struct DScene {
     const q4* spheres;   // 2 / sphere: {centre, radius} {radius^2, bits(material), 0, 0}
     const q4* tris;      // 3 / slot  : {v0, bits(global tri)} {e1=v1-v0, bits(material)} {e2=v2-v0, bits(rank = reference visiting order)}
     const q4* tri_attr;  // 2 / global triangle: {uv0, uv1} {uv2, 0, 0}
-    const q4* nodes;     // 2 / BVH2 node (32 B): both child boxes as 12 x 16-bit grid indices + 2 child refs
+    const q4* nodes;     // 4 / BVH4 node (64 B, one aligned fetch): four child boxes as 24 x 16-bit grid indices + 4 child refs
     f3 qbase, qscale;    // node grid: coordinate = qbase + q * qscale (one frame per scene)
     const DMaterial* materials;
     const DLight* lights; uint32_t num_lights;
@@ -106,9 +106,11 @@ enum : uint32_t { REF_LEAF = 0x80000000u, REF_NONE = 0x7FFFFFFFu };
 struct Counters { uint32_t nodes, tris, gates, rays; };
 
 struct Stack { uint32_t* p; uint32_t stride; };  // entry i lives at p[i*stride] (LDS: stride = threads per block)
-#define RT_STACK_DEPTH 32
+// Traversal stack: a 4-wide node pushes up to 3 children per level, the builders bound the depth at 13 four-wide
+// levels (25 two-wide ones), and up to RT_DEFER_ROOTS - 1 further mesh roots wait below: 3 * 13 + 7 = 46.
+#define RT_STACK_DEPTH 48
 #define RT_DEFER_ROOTS 8   // mesh roots one queued BVH item can carry
-#define RT_PENDING_MAX 2   // deferred mesh roots before the inline drain loop is forced (builder depth bound 24 + these < RT_STACK_DEPTH)
+#define RT_PENDING_MAX 2   // deferred mesh roots before the inline drain loop is forced
 
 struct Hit { float t; uint32_t prim; float u, v; uint32_t rank; };
 
@@ -338,8 +340,9 @@ RT_FN bool cull_box(const RayCull& c, float mnx, float mny, float mnz, float mxx
     return n <= f && n <= tbest;
 }
 
-// both child boxes of a 32-byte node {w0..w3}{w4,w5,ref0,ref1}: w = lo | hi<<16 over the sequence
-// lo0.x lo0.y lo0.z hi0.x hi0.y hi0.z lo1.x ... hi1.z
+// both child boxes of a 32-byte TWO-wide node {w0..w3}{w4,w5,ref0,ref1}: w = lo | hi<<16 over the sequence
+// lo0.x lo0.y lo0.z hi0.x hi0.y hi0.z lo1.x ... hi1.z.  This is the builders' intermediate format (binned SAH on
+// the host, LBVH on the device); the traversal reads the four-wide nodes that collapse_node() makes of it.
 RT_FN void node_test(const RayCull& rc, q4 n0, q4 n1, float tbest, bool& h0, bool& h1, float& t0, float& t1, uint32_t& r0, uint32_t& r1)
 {
     r0 = f2u(n1.z); r1 = f2u(n1.w);
@@ -347,60 +350,230 @@ RT_FN void node_test(const RayCull& rc, q4 n0, q4 n1, float tbest, bool& h0, boo
     h1 = cull_box(rc, q_lo(n0.w), q_hi(n0.w), q_lo(n1.x), q_hi(n1.x), q_lo(n1.y), q_hi(n1.y), tbest, t1);
 }
 
-template <bool STATS, bool ANYHIT>
-RT_FN bool bvh_drain(const DScene& S, f3 o, f3 d, const RayCull& rc, Hit& best, Stack st, uint32_t& sp, Counters& cnt)
+// ---- four-wide nodes (64 bytes: the unit the traversal kernels fetch) ------------------------------------
+// Node = {c0.x c0.y c0.z c1.x} {c1.y c1.z c2.x c2.y} {c2.z c3.x c3.y c3.z} {ref0 ref1 ref2 ref3}; word c.a = mn | mx<<16
+// (grid indices of child c's box on axis a).  An unused slot holds the inverted box mn = 65535, mx = 0, which no ray
+// near the scene passes, and `empty_ref`: a leaf of one degenerate triangle (all-zero record: det = 0, never hit) that
+// the builders append for this purpose — the margins of the box test grow with |o|, so a ray from very far away may
+// pass even an inverted box; it then tests a triangle that cannot be hit, and the traversal needs no "is there a
+// child" test.
+// collapse_node(): two-wide node i -> four-wide node i.  Child k of the two-wide node fills slots 2k, 2k+1: a leaf
+// fills one slot; an inner child is replaced by ITS two children (their boxes are tighter than the child's own).
+// Nodes on odd levels of the two-wide tree are no longer referenced.  Pure re-packing of integers: the host
+// builder and the device builder (rt_lbvh.hip) run the same function.
+RT_FN void collapse_node(const q4* nodes2, uint32_t i, uint32_t empty_ref, q4* out)
 {
-    // Pops references until the stack is empty.  The stack holds the roots of every Mesh whose
-    // reference gate passed plus deferred children (inner nodes and leaves alike), so all lanes
-    // of a wave sit in this one loop together.  "while-while" form: every lane first descends
-    // through inner nodes until it holds a leaf (or nothing), then the wave tests leaf triangles
-    // together, so the expensive exact triangle test is not re-issued on every node step.
+    uint32_t w[12], ref[4];
+    for (int k = 0; k < 12; ++k) w[k] = 0x0000FFFFu;   // mn = 65535, mx = 0
+    for (int k = 0; k < 4; ++k) ref[k] = empty_ref;
+    auto unpack = [](q4 a, q4 b, uint32_t* q) {
+        const uint32_t v[6] = {f2u(a.x), f2u(a.y), f2u(a.z), f2u(a.w), f2u(b.x), f2u(b.y)};
+        for (int k = 0; k < 6; ++k) { q[2 * k] = v[k] & 0xFFFFu; q[2 * k + 1] = v[k] >> 16; }
+    };
+    auto put = [&](int slot, const uint32_t* q6, uint32_t r) {   // q6 = {mn.xyz, mx.xyz}
+        for (int a = 0; a < 3; ++a) w[slot * 3 + a] = q6[a] | (q6[3 + a] << 16);
+        ref[slot] = r;
+    };
+    const q4 a0 = nodes2[(size_t)i * 2], a1 = nodes2[(size_t)i * 2 + 1];
+    uint32_t q[12];
+    unpack(a0, a1, q);
+    const uint32_t r2[2] = {f2u(a1.z), f2u(a1.w)};
+    for (int k = 0; k < 2; ++k) {
+        if (r2[k] == REF_NONE) continue;   // the absent second child of a one-leaf root
+        if (r2[k] & REF_LEAF) { put(2 * k, q + 6 * k, r2[k]); continue; }
+        const q4 b0 = nodes2[(size_t)r2[k] * 2], b1 = nodes2[(size_t)r2[k] * 2 + 1];
+        uint32_t g[12];
+        unpack(b0, b1, g);
+        const uint32_t gr[2] = {f2u(b1.z), f2u(b1.w)};
+        for (int j = 0; j < 2; ++j) if (gr[j] != REF_NONE) put(2 * k + j, g + 6 * j, gr[j]);
+    }
+    out[0] = {u2f(w[0]), u2f(w[1]), u2f(w[2]), u2f(w[3])};
+    out[1] = {u2f(w[4]), u2f(w[5]), u2f(w[6]), u2f(w[7])};
+    out[2] = {u2f(w[8]), u2f(w[9]), u2f(w[10]), u2f(w[11])};
+    out[3] = {u2f(ref[0]), u2f(ref[1]), u2f(ref[2]), u2f(ref[3])};
+}
+
+// Per-ray constants of the four-wide node test.  Same conservative slab test as cull_box, rearranged so that a
+// box costs 6 byte-permutes + 3 packed fmas + max3 + min3:
+//  * which plane of an axis is the entry and which the exit follows from the sign of d, so the ray carries, per
+//    axis, byte selectors that pick the entry / exit plane's 16 bits out of the word and the matching additive
+//    constants: no min/max per axis;
+//  * v_perm_b32 drops the 16 bits q into the mantissa of 2^23 (0x4B000000 | q = 2^23 + q exactly), so no integer
+//    conversion is needed: t = (2^23 + q) * s + (c - 2^23 * s).  The shifted constant is rounded to ~|s|/2 (half a
+//    grid step in t), so the entry constant is moved earlier and the exit constant later by delta >= that bound
+//    (0.51 |s| + 2^-20 |c|) on top of cull_box's margins — one more grid step of looseness, never a lost box;
+//  * entry and exit distance of an axis are the two halves of one packed fma.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float rt_v2f __attribute__((ext_vector_type(2)));   // a 64-bit register pair: the operand of v_pk_fma_f32
+#else
+struct rt_v2f { float x, y; };
+#endif
+// per axis: s = {qscale/d, the same}, c = {entry constant, exit constant}, p / q = byte selectors of the entry / exit plane
+// (everything a node step needs sits ready in registers: no per-step moves or selector arithmetic)
+struct RayCull4 { rt_v2f sx, sy, sz; rt_v2f cx, cy, cz; uint32_t px, py, pz, qx, qy, qz; };
+#define RT_PERM_LO 0x07040100u   // bytes {w.b0, w.b1, 0x00, 0x4B} of the pair {0x4B000000, w}
+#define RT_PERM_HI 0x07040302u   // bytes {w.b2, w.b3, 0x00, 0x4B}
+
+RT_FN RayCull4 make_cull4(const DScene& S, f3 o, f3 d)
+{
+    const RayCull c = make_cull(S, o, d);
+    RayCull4 r;
+    const float big = 8388608.0f, kd = 0.51f, kc = 1.0f / 1048576.0f;
+    // s >= 0 <=> d > 0 (qscale > 0): the lower plane (constant l, already moved earlier) is the entry
+    {
+        const bool pos = !(c.sx < 0.0f);
+        const float ne = pos ? c.lx : c.hx, fa = pos ? c.hx : c.lx;
+        r.sx.x = r.sx.y = c.sx; r.px = pos ? RT_PERM_LO : RT_PERM_HI; r.qx = pos ? RT_PERM_HI : RT_PERM_LO;
+        r.cx.x = (ne - (kd * fabsf(c.sx) + kc * fabsf(ne))) - big * c.sx;
+        r.cx.y = (fa + (kd * fabsf(c.sx) + kc * fabsf(fa))) - big * c.sx;
+    }
+    {
+        const bool pos = !(c.sy < 0.0f);
+        const float ne = pos ? c.ly : c.hy, fa = pos ? c.hy : c.ly;
+        r.sy.x = r.sy.y = c.sy; r.py = pos ? RT_PERM_LO : RT_PERM_HI; r.qy = pos ? RT_PERM_HI : RT_PERM_LO;
+        r.cy.x = (ne - (kd * fabsf(c.sy) + kc * fabsf(ne))) - big * c.sy;
+        r.cy.y = (fa + (kd * fabsf(c.sy) + kc * fabsf(fa))) - big * c.sy;
+    }
+    {
+        const bool pos = !(c.sz < 0.0f);
+        const float ne = pos ? c.lz : c.hz, fa = pos ? c.hz : c.lz;
+        r.sz.x = r.sz.y = c.sz; r.pz = pos ? RT_PERM_LO : RT_PERM_HI; r.qz = pos ? RT_PERM_HI : RT_PERM_LO;
+        r.cz.x = (ne - (kd * fabsf(c.sz) + kc * fabsf(ne))) - big * c.sz;
+        r.cz.y = (fa + (kd * fabsf(c.sz) + kc * fabsf(fa))) - big * c.sz;
+    }
+    return r;
+}
+
+// 0x4B000000 | (the half of w that `sel` names) as a float: 2^23 + q
+RT_FN float perm_q(uint32_t w, uint32_t sel)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return u2f(__builtin_amdgcn_perm(0x4B000000u, w, sel));
+#else
+    return u2f(0x4B000000u | ((sel & 0xFFu) == 0u ? (w & 0xFFFFu) : (w >> 16)));
+#endif
+}
+
+// entry / exit distance of one axis: {near, far} = {2^23 + q_near, 2^23 + q_far} * s + {c.x, c.y}
+RT_FN void slab_axis(uint32_t w, uint32_t sel_near, uint32_t sel_far, rt_v2f s, rt_v2f c, float& tn, float& tf)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const rt_v2f q = {perm_q(w, sel_near), perm_q(w, sel_far)};
+    const rt_v2f t = __builtin_elementwise_fma(q, s, c);   // v_pk_fma_f32
+    tn = t.x; tf = t.y;
+#else
+    tn = fmaf(perm_q(w, sel_near), s.x, c.x);
+    tf = fmaf(perm_q(w, sel_far), s.y, c.y);
+#endif
+}
+
+RT_FN bool cull_box4(const RayCull4& rc, uint32_t wx, uint32_t wy, uint32_t wz, float tbest, float& tnear)
+{
+    float ax, bx, ay, by, az, bz;
+    slab_axis(wx, rc.px, rc.qx, rc.sx, rc.cx, ax, bx);
+    slab_axis(wy, rc.py, rc.qy, rc.sy, rc.cy, ay, by);
+    slab_axis(wz, rc.pz, rc.qz, rc.sz, rc.cz, az, bz);
+    const float n = fmaxf(fmaxf(ax, ay), az), f = fminf(fminf(bx, by), bz);
+    tnear = n;
+    return n <= f && n <= tbest;
+}
+
+// the four child boxes of a 64-byte node (every slot holds a valid reference: see collapse_node)
+RT_FN void node_test4(const RayCull4& rc, q4 n0, q4 n1, q4 n2, q4 n3, float tbest, bool* h, float* t, uint32_t* r)
+{
+    r[0] = f2u(n3.x); r[1] = f2u(n3.y); r[2] = f2u(n3.z); r[3] = f2u(n3.w);
+    h[0] = cull_box4(rc, f2u(n0.x), f2u(n0.y), f2u(n0.z), tbest, t[0]);
+    h[1] = cull_box4(rc, f2u(n0.w), f2u(n1.x), f2u(n1.y), tbest, t[1]);
+    h[2] = cull_box4(rc, f2u(n1.z), f2u(n1.w), f2u(n2.x), tbest, t[2]);
+    h[3] = cull_box4(rc, f2u(n2.y), f2u(n2.z), f2u(n2.w), tbest, t[3]);
+}
+
+// compare-exchange of (distance, reference) pairs: afterwards ta <= tb
+RT_FN void order2(float& ta, uint32_t& ra, float& tb, uint32_t& rb)
+{
+    const bool sw = tb < ta;
+    const float t = sw ? tb : ta, u = sw ? ta : tb;
+    const uint32_t r = sw ? rb : ra, q = sw ? ra : rb;
+    ta = t; tb = u; ra = r; rb = q;
+}
+
+// One node: tests the four children and sorts them by entry distance (missed ones get distance +inf and sort
+// last).  Returns the number of hit children, which are r[0 .. n): r[0] is the nearest.
+RT_FN uint32_t node_children(const DScene& S, const RayCull4& rc, uint32_t node, float tbest, float* t, uint32_t* r)
+{
+    const q4* np = S.nodes + (size_t)node * 4;
+    const q4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    bool h[4];
+    node_test4(rc, n0, n1, n2, n3, tbest, h, t, r);
+    uint32_t nh = 0;
+    for (int c = 0; c < 4; ++c) {
+        nh += h[c] ? 1u : 0u;
+        t[c] = h[c] ? t[c] : INFINITY;   // a hit child's entry distance is <= tbest < inf
+    }
+    order2(t[0], r[0], t[1], r[1]); order2(t[2], r[2], t[3], r[3]);
+    order2(t[0], r[0], t[2], r[2]); order2(t[1], r[1], t[3], r[3]);
+    order2(t[1], r[1], t[2], r[2]);
+    return nh;
+}
+
+// The same test for the compacted kernel (rt_bvh.hip), sorted the other way round: hit children FARTHEST first,
+// missed ones (distance -inf) last, so that a lane can store all four {reference, distance} pairs at consecutive
+// stack positions without predication and advance its stack pointer by the number of hits: the nearest hit child
+// ends on top, what lies beyond the new top is never read.
+RT_FN uint32_t node_children_desc(const DScene& S, const RayCull4& rc, uint32_t node, float tbest, float* t, uint32_t* r)
+{
+    const q4* np = S.nodes + (size_t)node * 4;
+    const q4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    bool h[4];
+    node_test4(rc, n0, n1, n2, n3, tbest, h, t, r);
+    uint32_t nh = 0;
+    for (int c = 0; c < 4; ++c) {
+        nh += h[c] ? 1u : 0u;
+        t[c] = h[c] ? t[c] : -INFINITY;
+    }
+    order2(t[1], r[1], t[0], r[0]); order2(t[3], r[3], t[2], r[2]);
+    order2(t[2], r[2], t[0], r[0]); order2(t[3], r[3], t[1], r[1]);
+    order2(t[2], r[2], t[1], r[1]);
+    return nh;
+}
+
+template <bool STATS, bool ANYHIT>
+RT_FN bool bvh_drain(const DScene& S, f3 o, f3 d, const RayCull4& rc, Hit& best, Stack st, uint32_t& sp, Counters& cnt)
+{
+    // Pops references until the stack is empty.  The stack holds the roots of every Mesh whose reference gate
+    // passed plus deferred children (inner nodes and leaves alike).  The plain loop used wherever a ray is
+    // traversed in place (shadow rays, queue overflow, the host emulation); the compacted kernel k_bvh
+    // (rt_bvh.hip) walks the same nodes with its vote scheme and finds the same closest hit (ties by rank).
     bool found = false;
     if (sp == 0) return false;
     if (S.debug & 1u) { sp = 0; return false; }
-    uint32_t cur = st.p[(--sp) * st.stride];
-    while (cur != REF_NONE) {
-        while (!(cur & REF_LEAF)) {   // cur is an inner node (REF_NONE has bit 31 clear but never gets here: see pops)
-            const q4* n = S.nodes + (size_t)cur * 2;
-            q4 n0 = n[0], n1 = n[1];
+    while (sp > 0) {
+        const uint32_t cur = st.p[(--sp) * st.stride];
+        if (cur == REF_NONE) continue;
+        if (!(cur & REF_LEAF)) {
+            float t[4]; uint32_t r[4];
             if (STATS) cnt.nodes++;
-            uint32_t r0, r1;
-            float t0, t1;
-            bool h0, h1;
-            node_test(rc, n0, n1, best.t, h0, h1, t0, t1, r0, r1);
-            if (h0 && h1) {
-                bool swap = t1 < t0;
-                uint32_t nearc = swap ? r1 : r0, farc = swap ? r0 : r1;
-                if (sp < RT_STACK_DEPTH) st.p[(sp++) * st.stride] = farc;  // depth is bounded by the builder
-                cur = nearc;
-            } else if (h0) {
-                cur = r0;
-            } else if (h1) {
-                cur = r1;
-            } else {
-                if (sp == 0) { cur = REF_NONE; break; }
-                cur = st.p[(--sp) * st.stride];
-            }
+            const uint32_t nh = node_children(S, rc, cur, best.t, t, r);
+            // farthest first, so that the nearest child is popped next; depth is bounded by the builders
+            for (int c = 3; c >= 0; --c)
+                if ((uint32_t)c < nh && sp < RT_STACK_DEPTH) st.p[(sp++) * st.stride] = r[c];
+            continue;
         }
-        if (cur == REF_NONE) break;
-        {   // cur is a leaf: up to 8 triangles stored contiguously
-            uint32_t first = cur & 0x0FFFFFFFu, count = ((cur >> 28) & 7u) + 1u;
-            for (uint32_t i = 0; i < count; ++i) {
-                const q4* T = S.tris + (size_t)(first + i) * 3;
-                q4 a = T[0], b = T[1], e = T[2];
-                if (STATS) cnt.tris++;
-                float t, u, v;
-                if (tri_t(xyz(a), xyz(b), xyz(e), o, d, t, u, v)) {
-                    uint32_t rank = f2u(e.w);
-                    if (closer(t, rank, best)) {
-                        best.t = t; best.prim = H_TRI | (first + i); best.u = u; best.v = v; best.rank = rank;
-                        found = true;
-                        if (ANYHIT) { sp = 0; return true; }
-                    }
+        // cur is a leaf: up to 8 triangles stored contiguously
+        const uint32_t first = cur & 0x0FFFFFFFu, count = ((cur >> 28) & 7u) + 1u;
+        for (uint32_t i = 0; i < count; ++i) {
+            const q4* T = S.tris + (size_t)(first + i) * 3;
+            q4 a = T[0], b = T[1], e = T[2];
+            if (STATS) cnt.tris++;
+            float t, u, v;
+            if (tri_t(xyz(a), xyz(b), xyz(e), o, d, t, u, v)) {
+                uint32_t rank = f2u(e.w);
+                if (closer(t, rank, best)) {
+                    best.t = t; best.prim = H_TRI | (first + i); best.u = u; best.v = v; best.rank = rank;
+                    found = true;
+                    if (ANYHIT) { sp = 0; return true; }
                 }
             }
-            if (sp == 0) break;
-            cur = st.p[(--sp) * st.stride];
         }
     }
     return found;
@@ -422,6 +595,84 @@ RT_FN GateNode load_gate(const DScene& S, uint32_t i)
     return S.gates[i];
 }
 
+// The gate array's leading run of top-level Plane nodes (the room of the reference's scenes), read from the kernel
+// arguments in a wave-uniform loop (DScene::lead_planes).  Returns the index of the first node after them.
+RT_FN uint32_t lead_planes_hit(const DScene& S, f3 o, f3 d, Hit& best)
+{
+    for (uint32_t j = 0; j < S.num_lead_planes; ++j) {
+        const float* pl = S.lead_planes[j];
+        float t;
+        bool hit;
+        switch ((S.lead_axis >> (4u * j)) & 15u) {   // wave-uniform
+        case 0: hit = plane_axis_t(pl[0], o.x, d.x, t); break;
+        case 1: hit = plane_axis_t(pl[1], o.y, d.y, t); break;
+        case 2: hit = plane_axis_t(pl[2], o.z, d.z, t); break;
+        default: hit = plane_t(F3(pl[0], pl[1], pl[2]), F3(pl[3], pl[4], pl[5]), o, d, t); break;
+        }
+        if (hit && closer(t, f2u(pl[6]), best)) {
+            best.t = t; best.prim = H_PLANE | f2u(pl[7]); best.rank = f2u(pl[6]);
+        }
+    }
+    return S.num_lead_planes;
+}
+
+// The gate walk of an occlusion (AO) ray, resumable: closest hit among the primitives that are tested in place
+// (planes, spheres, free triangles) into `best`; the triangle-BVH root of every Mesh whose reference gates pass is
+// pushed on `st`.  Walks from node i until the array ends or RT_DEFER_ROOTS roots wait; returns the index to
+// resume at (>= S.num_gates: done).  Nothing is traversed here: the caller queues the roots for k_bvh and calls
+// again, so this walk needs 8 stack entries and no traversal code (the kernel that runs it stays small).
+template <bool STATS>
+RT_FN uint32_t walk_gates(const DScene& S, f3 o, f3 d, const RayGate& rg, uint32_t i, Hit& best, Stack st, uint32_t& sp, Counters& cnt)
+{
+    const uint32_t n = S.num_gates;
+    while (i < n && sp < RT_DEFER_ROOTS) {
+        const GateNode g = load_gate(S, i);
+        switch (g.kind & G_KIND_MASK) {
+        case G_GROUP:
+            i++;
+            break;
+        case G_GATED:
+            if (STATS) cnt.gates++;
+            i = ((g.kind & G_SAME_BOX) || (gate_maybe(g.mn, g.mx, rg) && (gate_surely(g.mn, g.mx, o, d, rg) || box_intersects(g.mn, g.mx, o, d)))) ? i + 1 : g.skip;
+            break;
+        case G_PLANE: {
+            float t;
+            if (plane_t(F3(g.mn[0], g.mn[1], g.mn[2]), F3(g.mx[0], g.mx[1], g.mx[2]), o, d, t) && closer(t, g.rank, best)) {
+                best.t = t; best.prim = H_PLANE | g.a; best.rank = g.rank;
+            }
+            i++;
+            break;
+        }
+        case G_SPHERE: {
+            float t;
+            if (sphere_t(F3(g.mn[0], g.mn[1], g.mn[2]), g.mx[0], o, d, t) && closer(t, g.rank, best)) {
+                best.t = t; best.prim = H_SPHERE | g.a; best.rank = g.rank;
+            }
+            i++;
+            break;
+        }
+        case G_TRI: {
+            const q4* T = S.tris + (size_t)g.a * 3;
+            q4 a = T[0], b = T[1], e = T[2];
+            if (STATS) cnt.tris++;
+            float t, u, v;
+            if (tri_t(xyz(a), xyz(b), xyz(e), o, d, t, u, v) && closer(t, g.rank, best)) {
+                best.t = t; best.prim = H_TRI | g.a; best.u = u; best.v = v; best.rank = g.rank;
+            }
+            i++;
+            break;
+        }
+        default:   // G_MESH
+            if (STATS) cnt.gates++;
+            if ((g.kind & G_SAME_BOX) || (gate_maybe(g.mn, g.mx, rg) && (gate_surely(g.mn, g.mx, o, d, rg) || box_intersects(g.mn, g.mx, o, d))))
+                st.p[(sp++) * st.stride] = g.a;
+            i++;
+            break;
+        }
+    }
+    return i;
+}
+
 // ---- one closest-hit query over world->scene ("one ray") ----------------------------------------
 // MODE 0: closest hit (`for obj in scene: hit |= obj->hit(ray, rec)`, main.cpp:1645-1648, 1390-1393,
 //         1457-1460, 1548-1551) with rec.t starting at tmax.
@@ -440,23 +691,7 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
     uint32_t cur_item = 0;
     uint32_t i = 0, sp = 0;
     const uint32_t n = S.num_gates;
-    if (MODE == 0) {   // the shadow query keeps per-entry state: it walks these nodes like any other
-        for (uint32_t j = 0; j < S.num_lead_planes; ++j) {
-            const float* pl = S.lead_planes[j];
-            float t;
-            bool hit;
-            switch ((S.lead_axis >> (4u * j)) & 15u) {   // wave-uniform
-            case 0: hit = plane_axis_t(pl[0], o.x, d.x, t); break;
-            case 1: hit = plane_axis_t(pl[1], o.y, d.y, t); break;
-            case 2: hit = plane_axis_t(pl[2], o.z, d.z, t); break;
-            default: hit = plane_t(F3(pl[0], pl[1], pl[2]), F3(pl[3], pl[4], pl[5]), o, d, t); break;
-            }
-            if (hit && closer(t, f2u(pl[6]), best)) {
-                best.t = t; best.prim = H_PLANE | f2u(pl[7]); best.rank = f2u(pl[6]);
-            }
-        }
-        i = S.num_lead_planes;
-    }
+    if (MODE == 0) i = lead_planes_hit(S, o, d, best);   // the shadow query keeps per-entry state: it walks these nodes like any other
     while (i < n) {
         const GateNode g = load_gate(S, i);
         if (MODE == 1 && g.item != cur_item) {
@@ -513,7 +748,7 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
             if ((g.kind & G_SAME_BOX) || (gate_maybe(g.mn, g.mx, rg) && (gate_surely(g.mn, g.mx, o, d, rg) || box_intersects(g.mn, g.mx, o, d)))) {
                 st.p[(sp++) * st.stride] = g.a;
                 if (sp >= (DEFER ? RT_DEFER_ROOTS : RT_PENDING_MAX)) {
-                    const RayCull rc = make_cull(S, o, d);
+                    const RayCull4 rc = make_cull4(S, o, d);
                     if (MODE == 1 && S.item_opaque[g.item]) {
                         if (bvh_drain<STATS, true>(S, o, d, rc, best, st, sp, cnt)) { shadowed = true; transparentOnly = false; i = n; break; }
                     } else {
@@ -527,7 +762,7 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
         }
         // end of the walk, or (shadow query) end of a world->scene entry: drain the deferred meshes
         if (!DEFER && sp > 0 && (i >= n || (MODE == 1 && load_gate(S, i).item != cur_item))) {
-            const RayCull rc = make_cull(S, o, d);
+            const RayCull4 rc = make_cull4(S, o, d);
             if (MODE == 1 && S.item_opaque[cur_item]) {
                 if (bvh_drain<STATS, true>(S, o, d, rc, best, st, sp, cnt)) { shadowed = true; transparentOnly = false; i = n; }
             } else {

@@ -65,10 +65,14 @@ __global__ void __launch_bounds__(RT_BLOCK) k_raygen(DScene S, RenderArgs A, Bat
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) raygen_item(S, A, B, i);
 }
 
+// One wave per entry of Batch::ao_ovf (k_trace_overflow, k_ao_overflow); normally there is none and the blocks leave at once.
+#define RT_OVF_BLOCK 64
+
+// The closest-hit kernel traverses nothing (trace_item): a stack of RT_DEFER_ROOTS mesh roots per lane is all it needs.
 template <bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK) k_trace(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
 {
-    __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_BLOCK];
+    __shared__ uint32_t s_stack[RT_DEFER_ROOTS * RT_BLOCK];
     __shared__ GateNode s_gates[RT_LDS_GATES];
     stage_gates(S, s_gates);
     const uint32_t n = depth == 0 ? fixed_n : B.counters[C_QUEUE + depth];
@@ -78,9 +82,29 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace(DScene S, RenderArgs A, Batc
     // wave-uniform trip count: every lane of a wave takes part in the queue cursor's ballots
     for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
         const uint32_t i = base + threadIdx.x;
-        trace_item<STATS>(S, A, B, depth, i, i < n, st, cnt, qc);
+        bool overflow = false;
+        trace_item<STATS>(S, A, B, depth, i, i < n, st, cnt, qc, overflow);
+        if (__builtin_amdgcn_ballot_w64(overflow) != 0ull && (threadIdx.x & 63u) == 0u) {   // the wave's rays are redone by k_trace_overflow
+            const uint32_t e = atomicAdd(&B.counters[C_TR_OVF + depth], 1u);
+            if (e < B.ovf_cap) B.ao_ovf[e] = base + (threadIdx.x & ~63u);
+        }
     }
     close_cursor(qc, B.bq_roots, (uint32_t)REF_NONE, B.cq_cap);
+    flush_counters<STATS>(cnt, B.stats, 0);
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(RT_OVF_BLOCK) k_trace_overflow(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
+{
+    const uint32_t count = B.counters[C_TR_OVF + depth] < B.ovf_cap ? B.counters[C_TR_OVF + depth] : B.ovf_cap;
+    if (blockIdx.x >= count) return;
+    __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_OVF_BLOCK];
+    __shared__ GateNode s_gates[RT_LDS_GATES];
+    stage_gates(S, s_gates);
+    const uint32_t n = depth == 0 ? fixed_n : B.counters[C_QUEUE + depth];
+    Stack st{s_stack + threadIdx.x, RT_OVF_BLOCK};
+    Counters cnt{0, 0, 0, 0};
+    for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) trace_overflow_item<STATS>(S, A, B, depth, B.ao_ovf[e], threadIdx.x, n, st, cnt);
     flush_counters<STATS>(cnt, B.stats, 0);
 }
 
@@ -114,10 +138,11 @@ __global__ void __launch_bounds__(RT_SHADOW_BLOCK) k_shadow(DScene S, RenderArgs
     flush_counters<STATS>(cnt, B.stats, 1);
 }
 
+// The hot AO kernel traverses nothing (ao_item): a stack of RT_DEFER_ROOTS mesh roots per lane is all it needs.
 template <bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
 {
-    __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_BLOCK];
+    __shared__ uint32_t s_stack[RT_DEFER_ROOTS * RT_BLOCK];
     __shared__ GateNode s_gates[RT_LDS_GATES];
     stage_gates(S, s_gates);
     const uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
@@ -129,9 +154,30 @@ __global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B
     // wave-uniform trip count: every lane of a wave takes part in the queue cursor's ballots
     for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
         const uint32_t i = base + threadIdx.x;
-        ao_item<STATS>(S, A, B, depth, base, threadIdx.x, nslots, i < n, st, cnt, qc);
+        bool overflow = false;
+        ao_item<STATS>(S, A, B, depth, base, threadIdx.x, nslots, i < n, st, cnt, qc, overflow);
+        if (__builtin_amdgcn_ballot_w64(overflow) != 0ull && (threadIdx.x & 63u) == 0u) {   // queue full: the wave's rays are redone by k_ao_overflow
+            const uint32_t e = atomicAdd(&B.counters[C_AO + depth], 1u);
+            if (e < B.ovf_cap) B.ao_ovf[e] = base + (threadIdx.x & ~63u);
+        }
     }
     close_cursor(qc, B.bq_roots, (uint32_t)REF_NONE, B.bq_cap);
+    flush_counters<STATS>(cnt, B.stats, 2);
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(RT_OVF_BLOCK) k_ao_overflow(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
+{
+    const uint32_t count = B.counters[C_AO + depth] < B.ovf_cap ? B.counters[C_AO + depth] : B.ovf_cap;
+    if (blockIdx.x >= count) return;
+    __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_OVF_BLOCK];
+    __shared__ GateNode s_gates[RT_LDS_GATES];
+    stage_gates(S, s_gates);
+    const uint32_t nslots = depth == 0 ? fixed_n : B.counters[C_QUEUE + depth];
+    Stack st{s_stack + threadIdx.x, RT_OVF_BLOCK};
+    Counters cnt{0, 0, 0, 0};
+    for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) ao_overflow_item<STATS>(S, A, B, B.ao_ovf[e], threadIdx.x, nslots, st, cnt);
+    cnt.rays = 0;   // counted by k_ao
     flush_counters<STATS>(cnt, B.stats, 2);
 }
 
@@ -329,6 +375,13 @@ struct GpuBackend {
             else hipLaunchKernelGGL(k_trace<false>, dim3(grid_d(d, n, RT_GRID_TRACE)), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
         });
     }
+    void trace_overflow(const RenderArgs& A, int d, uint32_t n)
+    {
+        timed(RT_K_TRACE, [&] {
+            if (stats) hipLaunchKernelGGL(k_trace_overflow<true>, dim3(RT_MAX_GRID), dim3(RT_OVF_BLOCK), 0, stream, S, A, B, d, n);
+            else hipLaunchKernelGGL(k_trace_overflow<false>, dim3(RT_MAX_GRID), dim3(RT_OVF_BLOCK), 0, stream, S, A, B, d, n);
+        });
+    }
     void bvh_trace(const RenderArgs& A, int d)
     {
         timed(RT_K_TRACE_BVH, [&] {
@@ -361,6 +414,14 @@ struct GpuBackend {
             else hipLaunchKernelGGL(k_ao<false>, dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
         });
     }
+    void ao_overflow(const RenderArgs& A, int d, uint32_t n)
+    {
+        if (S.ambient.occlusion_samples <= 0) return;
+        timed(RT_K_AO, [&] {
+            if (stats) hipLaunchKernelGGL(k_ao_overflow<true>, dim3(RT_MAX_GRID), dim3(RT_OVF_BLOCK), 0, stream, S, A, B, d, n);
+            else hipLaunchKernelGGL(k_ao_overflow<false>, dim3(RT_MAX_GRID), dim3(RT_OVF_BLOCK), 0, stream, S, A, B, d, n);
+        });
+    }
     void shade(const RenderArgs& A, int d, uint32_t n) { timed(RT_K_SHADE, [&] { hipLaunchKernelGGL(k_shade, dim3(grid_d(d, n, RT_GRID_SHADE)), dim3(RT_BLOCK), 0, stream, S, A, B, d, n); }); }
     void resolve(const RenderArgs& A, uint32_t n) { timed(RT_K_RESOLVE, [&] { hipLaunchKernelGGL(k_resolve, dim3(grid_for(n)), dim3(RT_BLOCK), 0, stream, S, A, B, n, levels_run); }); }
 };
@@ -384,7 +445,9 @@ size_t carve_batch(Batch& B, char* base, uint32_t P, int levels, uint32_t nl, ui
     // slot would be lost, so this bound is the true worst case; the BVH queues below fall back to inline traversal.)
     B.sh_cap = (uint32_t)std::min<size_t>(2 * (size_t)P * nl + (size_t)RT_GRID_PREP * (RT_BLOCK / 64) * RT_SHCHUNK, 0xFFFF0000u);
     B.sh_queue = (uint32_t*)take(4ull * B.sh_cap);
-    B.ao_t = (float*)take(4ull * P * (n2 ? n2 : 1));
+    B.ao_key = (uint32_t*)take(4ull * P * (n2 ? n2 : 1));
+    B.ovf_cap = (uint32_t)((uint64_t)P * (n2 ? n2 : 1) / 64u + 8u);   // one entry per wave and 64 items at most
+    B.ao_ovf = (uint32_t*)take(4ull * B.ovf_cap);
     B.sh_res = (float*)take(4ull * P * nl);
     B.lvl = (q4*)take(sizeof(q4) * (size_t)P * levels);
     B.lvl_ph = (float*)take(4ull * P * levels * (nl > 1 ? nl - 1 : 1));
@@ -403,7 +466,7 @@ size_t carve_batch(Batch& B, char* base, uint32_t P, int levels, uint32_t nl, ui
     B.bq_b = (q4*)take(sizeof(q4) * (size_t)B.bq_cap);
     B.bq_c = (q4*)take(sizeof(q4) * (size_t)B.cq_cap);
     B.bq_roots = (uint32_t*)take(4ull * RT_DEFER_ROOTS * (size_t)B.bq_cap);
-    B.bq_spill = (uint32_t*)take(4ull * (RT_STACK_DEPTH - RT_LDS_STACK) * RT_BVH_GRID * RT_BVH_BLOCK);
+    B.bq_spill = (uint32_t*)take(8ull * (RT_STACK_DEPTH - RT_LDS_STACK) * RT_BVH_GRID * RT_BVH_BLOCK);   // {reference, entry distance}
     return off;
 }
 } // namespace

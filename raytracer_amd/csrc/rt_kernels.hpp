@@ -12,7 +12,7 @@
 #define RT_MAX_GRID (256 * 8)   // persistent k_bvh, and the default of the grid-stride kernels
 #endif
 #ifndef RT_LDS_STACK
-#define RT_LDS_STACK 12      // k_bvh: stack entries per lane kept in LDS; deeper ones spill to global memory (rare)
+#define RT_LDS_STACK 14      // k_bvh: stack entries per lane kept in LDS; deeper ones spill to global memory (rare)
 #endif
 #ifndef RT_BVH_BLOCK
 #define RT_BVH_BLOCK RT_BLOCK   // threads per block and blocks of the persistent kernel (swept 64-512 / 1024-8192: no effect)

@@ -1,6 +1,7 @@
 // rt_lbvh.hip — SURVEY 8f N1: the triangle BVHs of a scene built on the device (LBVH: Morton codes, one
 // radix sort, Karras' radix tree, bottom-up box fit), in the formats the traversal kernels read: 48-byte
-// triangle records in leaf order and 32-byte quantised two-child nodes with <= 2 triangles per leaf.
+// triangle records in leaf order and 64-byte quantised four-child nodes (collapsed from the two-child radix
+// tree) with <= 2 triangles per leaf.
 //
 // The reference has no counterpart (its Mesh::hit scans every triangle, main.cpp:890-912); on this path a
 // BVH only culls, so a frame rendered with these trees is bit-identical to one rendered with the host's
@@ -218,7 +219,7 @@ __global__ void __launch_bounds__(LB_BLOCK) k_nodes(const DOcc* mocc, uint32_t n
     const float base[3] = {qbase.x, qbase.y, qbase.z}, scale[3] = {qscale.x, qscale.y, qscale.z};
     uint32_t q[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ref[2] = {0, 0};
     if (o.n <= 2) {
-        // one root node: the leaf, and the same leaf again behind a box of one grid point (rt_scene.cpp)
+        // one root node over the leaf; no second child (rt_scene.cpp)
         if (i != 0) { nodes[(size_t)g * 2] = q4{0, 0, 0, 0}; nodes[(size_t)g * 2 + 1] = q4{0, 0, 0, 0}; return; }
         const float ext = 1023.0f;
         for (int a = 0; a < 3; ++a) {
@@ -226,7 +227,8 @@ __global__ void __launch_bounds__(LB_BLOCK) k_nodes(const DOcc* mocc, uint32_t n
             q[a] = quant(o.mn[a], base[a], scale[a], false);
             q[3 + a] = quant(mx, base[a], scale[a], true);
         }
-        ref[0] = ref[1] = REF_LEAF | ((o.n - 1u) << 28) | o.slot_off;
+        ref[0] = REF_LEAF | ((o.n - 1u) << 28) | o.slot_off;
+        ref[1] = REF_NONE;
     } else {
         if (T.hi[g] - T.lo[g] + 1u < 3u) { nodes[(size_t)g * 2] = q4{0, 0, 0, 0}; nodes[(size_t)g * 2 + 1] = q4{0, 0, 0, 0}; return; }   // became a leaf
         const uint32_t child[2] = {T.left[g], T.right[g]};
@@ -248,6 +250,16 @@ __global__ void __launch_bounds__(LB_BLOCK) k_nodes(const DOcc* mocc, uint32_t n
     for (int k = 0; k < 6; ++k) w[k] = q[2 * k] | (q[2 * k + 1] << 16);
     nodes[(size_t)g * 2] = q4{u2f(w[0]), u2f(w[1]), u2f(w[2]), u2f(w[3])};
     nodes[(size_t)g * 2 + 1] = q4{u2f(w[4]), u2f(w[5]), u2f(ref[0]), u2f(ref[1])};
+}
+
+// two-wide quantised nodes -> the four-wide nodes the traversal fetches (collapse_node, rt_core.hpp)
+__global__ void __launch_bounds__(LB_BLOCK) k_collapse(const q4* nodes2, uint32_t nnodes, uint32_t empty_ref, q4* nodes4)
+{
+    const uint32_t g = blockIdx.x * LB_BLOCK + threadIdx.x;
+    if (g >= nnodes) return;
+    q4 out[4];
+    collapse_node(nodes2, g, empty_ref, out);
+    for (int k = 0; k < 4; ++k) nodes4[(size_t)g * 4 + k] = out[k];
 }
 
 struct Scratch {
@@ -284,8 +296,10 @@ int lbvh_build(const HostScene& H, hipStream_t stream, uint32_t max_ok, q4** d_t
     *d_tris = nullptr; *d_nodes = nullptr; *max_depth = 0;
     // results (owned by the caller on success)
     q4 *tris = nullptr, *nodes = nullptr;
-    LBCHECK(hipMalloc((void**)&tris, std::max<size_t>(16, (size_t)nslots * 3 * sizeof(q4))));
-    if (hipMalloc((void**)&nodes, std::max<size_t>(16, (size_t)nnodes * 2 * sizeof(q4))) != hipSuccess) { (void)hipFree(tris); err = "lbvh_build: out of device memory"; return RT_ERR_HIP; }
+    // one more slot than the layout has: the degenerate triangle that unused node slots refer to (collapse_node)
+    LBCHECK(hipMalloc((void**)&tris, ((size_t)nslots + 1) * 3 * sizeof(q4)));
+    LBCHECK(hipMemsetAsync(tris + (size_t)nslots * 3, 0, 3 * sizeof(q4), stream));
+    if (hipMalloc((void**)&nodes, std::max<size_t>(16, (size_t)nnodes * 4 * sizeof(q4))) != hipSuccess) { (void)hipFree(tris); err = "lbvh_build: out of device memory"; return RT_ERR_HIP; }
     auto fail = [&](const std::string& m) { (void)hipFree(tris); (void)hipFree(nodes); err = m; return (int)RT_ERR_HIP; };
     if (nslots == 0) { *d_tris = tris; *d_nodes = nodes; if (seconds) *seconds = 0.0; return RT_OK; }
 
@@ -293,7 +307,9 @@ int lbvh_build(const HostScene& H, hipStream_t stream, uint32_t max_ok, q4** d_t
     rt_triangle* d_tri = nullptr; DOcc *d_all = nullptr, *d_mesh = nullptr;
     unsigned long long *k0 = nullptr, *k1 = nullptr; uint32_t *v0 = nullptr, *v1 = nullptr, *d_depth = nullptr;
     Tree T{};
+    q4* nodes2 = nullptr;   // two-wide nodes, collapsed into `nodes` at the end
     hipError_t e = hipSuccess;
+    if ((e = S.get(&nodes2, (size_t)nnodes * 2)) != hipSuccess) return fail(std::string("lbvh_build: hipMalloc: ") + hipGetErrorString(e));
     if ((e = S.get(&d_tri, H.triangles.size())) || (e = S.get(&d_all, all.size())) || (e = S.get(&d_mesh, mesh.size())) ||
         (e = S.get(&k0, nslots)) || (e = S.get(&k1, nslots)) || (e = S.get(&v0, nslots)) || (e = S.get(&v1, nslots)) || (e = S.get(&d_depth, 1)) ||
         (e = S.get(&T.left, nnodes)) || (e = S.get(&T.right, nnodes)) || (e = S.get(&T.lo, nnodes)) || (e = S.get(&T.hi, nnodes)) ||
@@ -331,7 +347,8 @@ int lbvh_build(const HostScene& H, hipStream_t stream, uint32_t max_ok, q4** d_t
     if (nnodes) {
         hipLaunchKernelGGL(k_fit, dim3(gs), dim3(LB_BLOCK), 0, stream, d_tri, d_all, (uint32_t)all.size(), v1, nslots, T);
         hipLaunchKernelGGL(k_nodes, dim3(gn), dim3(LB_BLOCK), 0, stream, d_mesh, (uint32_t)mesh.size(), nnodes, T,
-                           F3(H.qbase[0], H.qbase[1], H.qbase[2]), F3(H.qscale[0], H.qscale[1], H.qscale[2]), nodes);
+                           F3(H.qbase[0], H.qbase[1], H.qbase[2]), F3(H.qscale[0], H.qscale[1], H.qscale[2]), nodes2);
+        hipLaunchKernelGGL(k_collapse, dim3(gn), dim3(LB_BLOCK), 0, stream, nodes2, nnodes, (uint32_t)REF_LEAF | nslots, nodes);
     }
     if ((e = hipGetLastError()) != hipSuccess) return fail(std::string("lbvh_build: launch: ") + hipGetErrorString(e));
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail(std::string("lbvh_build: ") + hipGetErrorString(e));

@@ -8,10 +8,12 @@
 //   for depth d = 0 .. max_depth+1 over the per-depth path queue:
 //     trace           [for obj in world->scene: obj->hit(), main.cpp:1645-1648 / 1457-1460 / 1548-1551]
 //     bvh (trace)     [the Mesh::hit triangle loops of the rays whose gates passed, main.cpp:890-912, compacted]
+//     trace_overflow  [rays with more Meshes than a queue item carries / a full queue, traversed in place]
 //     prep            [hit attributes; Reflective::rho / Transparency::rho ray set-up, main.cpp:1437-1468, 1525-1592]
 //     shadow          [Material::shadowed, main.cpp:40-76]
 //     ao              [Ambient::L's n x n rays, main.cpp:1361-1404]
 //     bvh (ao)        [their Mesh::hit triangle loops, compacted]
+//     ao_overflow     [the AO rays of waves that found the work queue full, traversed in place; normally none]
 //     shade           [Matte/Specular/Textured/Mirror/Refraction::shade, main.cpp:1143-1299, 1487-1511, 1607-1616]
 //   resolve           [per-level `L = clamp(local + child)` unwound deepest first; pixel average main.cpp:1656-1658]
 #pragma once
@@ -20,8 +22,8 @@
 namespace rt {
 
 enum : uint8_t { LK_NONE = 0, LK_TERMINAL = 1, LK_MIRROR = 2, LK_REFRACT = 3 };
-// (C_AO is unused since AO work became positional: slot = path index)
-enum { C_QUEUE = 0, C_AO = 64, C_SH = 128, C_BQ = 192, C_BQA = 256, C_BQ_NEXT = 320, C_BQA_NEXT = 384, C_TOTAL = 448 };   // per-batch u32 counters, one per depth
+// (C_AO counts the entries of Batch::ao_ovf)
+enum { C_QUEUE = 0, C_AO = 64, C_SH = 128, C_BQ = 192, C_BQA = 256, C_BQ_NEXT = 320, C_BQA_NEXT = 384, C_TR_OVF = 448 /* entries of Batch::ao_ovf written by k_trace */, C_TOTAL = 512 };   // per-batch u32 counters, one per depth
 enum { ST_SHADOW = 0, ST_AO = 1, ST_BOUNCE = 2, ST_NODES = 3, ST_TRIS = 6, ST_GATES = 9, ST_BVHRAYS = 12,
        ST_DIAG = 15 /* k_bvh<AO> lane-packing diagnostics of the counting variant: node steps, lanes in them, triangle steps, lanes in them, votes, active lanes at votes, refills, lanes refilled */,
        ST_TOTAL = 23 }; // u64
@@ -40,7 +42,10 @@ struct Batch {
     q4* ao_o; q4* ao_u; q4* ao_w;
     uint32_t* ao_slot;     // per path: its slot, 0xFFFFFFFF = none
     uint32_t* sh_queue;    // p * num_lights + light
-    float* ao_t;           // [slot * n*n + k]  closest distance (occlusion_dist when nothing was hit)
+    uint32_t* ao_key;      // [slot * n*n + k]  closest distance as an ordered key (t_key; occlusion_dist when nothing was hit):
+                           // k_ao stores the closest of the primitives it tests in place, k_bvh / k_ao_overflow take minima
+    uint32_t* ao_ovf;      // waves of k_ao (first item index) that found the BVH work queue full: redone by k_ao_overflow
+    uint32_t ovf_cap;
     float* sh_res;         // [p * num_lights + light]
     q4* lvl;               // [d*P + p]  TERMINAL: final colour; MIRROR: {ambient term, phong of light 0}
     float* lvl_ph;         // [(d*P + p)*(num_lights-1) + (l-1)] phong of lights 1..
@@ -113,6 +118,27 @@ __device__ inline uint32_t queue_slot(uint32_t* counter)
 #else
 inline uint32_t queue_slot(uint32_t* counter) { return (*counter)++; }
 #endif
+
+// Ordered key of a ray parameter: unsigned order of the keys = order of the floats (t may be negative),
+// so that several work items of one occlusion ray can combine their distances with an integer atomic minimum.
+RT_FN uint32_t t_key(float t) { const uint32_t b = f2u(t); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
+RT_FN float key_t(uint32_t k) { return u2f(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
+RT_FN void key_min(uint32_t* p, uint32_t k)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMin(p, k);
+#else
+    if (k < *p) *p = k;
+#endif
+}
+RT_FN bool wave_any(bool x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(x) != 0ull;
+#else
+    return x;
+#endif
+}
 
 // ---- kernel bodies --------------------------------------------------------------------------------
 RT_FN void raygen_item(const DScene& S, const RenderArgs& A, const Batch& B, uint32_t p)
@@ -200,36 +226,18 @@ RT_FN void close_cursor(const QCursor& qc, uint32_t* holes, uint32_t hole_value,
 #endif
 }
 
-// Queue a ray whose Mesh gates passed for the compacted BVH kernel, through the chunked cursor (GPU: all 64
-// lanes of the wave call it, `want` selects); falls back to traversing inline when the queue is full.
-// `best` is the closest hit among the non-mesh primitives.  AO = 1: occlusion ray (no hit record travels).
-template <bool AO, bool STATS>
-RT_FN bool defer_bvh(const DScene& S, const Batch& B, uint32_t counter, bool want, f3 o, f3 d, Hit& best, uint32_t dst,
-                     Stack st, uint32_t sp, Counters& cnt, QCursor& qc)
-{
-    const uint32_t cap = AO ? B.bq_cap : B.cq_cap;
-    const uint32_t slot = chunk_append<RT_QCHUNK>(&B.counters[counter], want, qc, B.bq_roots, (uint32_t)REF_NONE, cap);
-    if (!want) return false;
-    if (slot >= cap) {
-        RayCull rc = make_cull(S, o, d);
-        bvh_drain<STATS, false>(S, o, d, rc, best, st, sp, cnt);
-        return false;
-    }
-    q4 a = {o.x, o.y, o.z, best.t};
-    q4 b = {d.x, d.y, d.z, u2f(dst | ((sp - 1u) << 29))};   // dst < 2^29 (checked where the batch is sized); 1 <= sp <= RT_DEFER_ROOTS
-    B.bq_a[slot] = a; B.bq_b[slot] = b;
-    if (!AO) { q4 c = {u2f(best.prim), u2f(best.rank), best.u, best.v}; B.bq_c[slot] = c; }
-    for (uint32_t k = 0; k < sp; ++k) B.bq_roots[(size_t)k * B.bq_cap + slot] = st.p[k * st.stride];
-    return true;
-}
-
+// One closest-hit query (the scene loop of raytrace(), Reflective::rho, Transparency::rho).  Like ao_item the hot
+// kernel traverses nothing: planes / spheres / free triangles are tested in place, the roots of the Meshes whose
+// gates pass ride in ONE queue item for k_bvh (a closest-hit record cannot be combined from several items the way
+// a distance can).  A ray with more than RT_DEFER_ROOTS such Meshes, or one that finds the queue full, sets
+// `overflow`: its wave's rays are redone, traversed in place, by trace_overflow_item after k_bvh has run.
 // GPU: called by all 64 lanes of a wave (`valid` = false for lanes without an item): the queue cursor votes
 template <bool STATS>
-RT_FN void trace_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, bool valid, Stack st, Counters& cnt, QCursor& qc)
+RT_FN void trace_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, bool valid, Stack st, Counters& cnt, QCursor& qc, bool& overflow)
 {
     uint32_t p = 0, sp = 0;
     f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
-    Hit h = {}; float sh;
+    Hit h; h.t = FLT_MAX; h.prim = H_MISS; h.u = 0; h.v = 0; h.rank = 0;
     if (valid) {
         p = item_path(A, B, depth, idx);
         valid = !(depth == 0 && !path_of(A, p).valid);
@@ -237,10 +245,40 @@ RT_FN void trace_item(const DScene& S, const RenderArgs& A, const Batch& B, int 
     if (valid) {
         const q4 o4 = B.ray_o[depth & 1][p], d4 = B.ray_d[depth & 1][p];
         o = xyz(o4); d = xyz(d4);
-        sp = trace<0, STATS, true>(S, o, d, FLT_MAX, h, sh, st, cnt);
+        if (!(S.debug & 2u)) {
+            const RayGate rg = make_gate(S.cull_pad, S.extent, o, d);
+            uint32_t i = lead_planes_hit(S, o, d, h);
+            i = walk_gates<STATS>(S, o, d, rg, i, h, st, sp, cnt);
+            if (i < S.num_gates) { overflow = true; sp = 0; }   // more Meshes than one item carries
+        }
     }
-    if (defer_bvh<false, STATS>(S, B, C_BQ + depth, sp > 0, o, d, h, p, st, sp, cnt, qc)) return;
+    const bool want = sp > 0;
+    const uint32_t slot = chunk_append<RT_QCHUNK>(&B.counters[C_BQ + depth], want, qc, B.bq_roots, (uint32_t)REF_NONE, B.cq_cap);
+    if (want && slot < B.cq_cap) {
+        const q4 a = {o.x, o.y, o.z, h.t};
+        const q4 b = {d.x, d.y, d.z, u2f(p | ((sp - 1u) << 29))};   // p < 2^29 (checked where the batch is sized); 1 <= sp <= RT_DEFER_ROOTS
+        const q4 c = {u2f(h.prim), u2f(h.rank), h.u, h.v};
+        B.bq_a[slot] = a; B.bq_b[slot] = b; B.bq_c[slot] = c;
+        for (uint32_t k = 0; k < sp; ++k) B.bq_roots[(size_t)k * B.bq_cap + slot] = st.p[k * st.stride];
+        return;   // k_bvh writes hit[p]
+    }
+    if (want) overflow = true;   // queue full
     if (!valid) return;
+    q4 r = {h.t, u2f(h.prim), h.u, h.v};
+    B.hit[p] = r;
+}
+
+// The rays of a wave of trace_item that set `overflow`, each traversed in place.  `entry` = the wave's first item.
+template <bool STATS>
+RT_FN void trace_overflow_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t entry, uint32_t lane, uint32_t n, Stack st, Counters& cnt)
+{
+    const uint32_t idx = entry + lane;
+    if (idx >= n) return;
+    const uint32_t p = item_path(A, B, depth, idx);
+    if (depth == 0 && !path_of(A, p).valid) return;
+    const q4 o4 = B.ray_o[depth & 1][p], d4 = B.ray_d[depth & 1][p];
+    Hit h; float sh;
+    trace<0, STATS, false>(S, xyz(o4), xyz(d4), FLT_MAX, h, sh, st, cnt);
     q4 r = {h.t, u2f(h.prim), h.u, h.v};
     B.hit[p] = r;
 }
@@ -254,7 +292,7 @@ RT_FN void bvh_item(const DScene& S, const Batch& B, uint32_t idx, Stack st, Cou
     f3 o = xyz(a), d = xyz(b);
     Hit best; best.t = a.w; best.prim = H_MISS; best.rank = 0; best.u = 0; best.v = 0;
     if (!AO) { q4 c = B.bq_c[idx]; best.prim = f2u(c.x); best.rank = f2u(c.y); best.u = c.z; best.v = c.w; }
-    RayCull rc = make_cull(S, o, d);
+    RayCull4 rc = make_cull4(S, o, d);
     const uint32_t nroots = (f2u(b.w) >> 29) + 1u, dst = f2u(b.w) & 0x1FFFFFFFu;
     if (B.bq_roots[idx] == REF_NONE) return;   // hole
     for (uint32_t k = 0; k < nroots; ++k) {
@@ -262,7 +300,7 @@ RT_FN void bvh_item(const DScene& S, const Batch& B, uint32_t idx, Stack st, Cou
         st.p[0] = B.bq_roots[(size_t)k * B.bq_cap + idx];
         bvh_drain<STATS, false>(S, o, d, rc, best, st, sp, cnt);
     }
-    if (AO) B.ao_t[dst] = best.t;
+    if (AO) key_min(&B.ao_key[dst], t_key(best.t));
     else { q4 r = {best.t, u2f(best.prim), best.u, best.v}; B.hit[dst] = r; }
 }
 
@@ -381,32 +419,40 @@ RT_FN void shadow_item(const DScene& S, const RenderArgs& A, const Batch& B, int
     B.sh_res[e] = sh;
 }
 
+// AO work item -> (slot, stratum k).  Blocked stratum-major order: RT_AO_BLOCK consecutive slots x all n*n
+// strata, stratum by stratum, so a wave traces the same stratum (x,y) of 64 neighbouring hits, whose rays leave
+// nearby points in similar directions, and the 16 passes over a block's hit records (~70 B each) are served by L2.
+// item = base + off with base a multiple of 256 that is the same for the whole workgroup (GPU) and off < 256:
+// block and stratum come from `base` alone, i.e. from scalar registers.
+RT_FN void ao_coords(const DScene& S, uint32_t nslots, uint32_t base, uint32_t off, uint32_t& slot, uint32_t& k)
+{
+    const uint32_t n2b = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
+    const uint32_t nfull = nslots & ~(RT_AO_BLOCK - 1u);
+    if (base < nfull * n2b) {
+        const uint32_t b = base / (RT_AO_BLOCK * n2b), r = base % (RT_AO_BLOCK * n2b);
+        k = r / RT_AO_BLOCK; slot = b * RT_AO_BLOCK + (r & (RT_AO_BLOCK - 1u)) + off;
+    } else {
+        const uint32_t r = base + off - nfull * n2b, tail = nslots - nfull;
+        k = r / tail; slot = nfull + r % tail;
+    }
+}
+
+// One AO ray (Ambient::L's inner loop, main.cpp:1372-1398).  The hot kernel traverses nothing: it walks the gate
+// nodes, tests planes / spheres / free triangles in place and queues the triangle-BVH roots of the Meshes whose
+// gates pass for k_bvh — one queue item per RT_DEFER_ROOTS roots, as many items as the ray needs.  All of a ray's
+// distances (its own and its items') meet in ao_key[dst] by minimum.  A wave that finds the queue full sets
+// `overflow`: its 64 rays are redone by ao_overflow_item.
+// GPU: called by all 64 lanes of a wave (`valid` = false for lanes without an item): the queue cursor votes.
 template <bool STATS>
 RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t base, uint32_t off, uint32_t nslots, bool valid, Stack st,
-                   Counters& cnt, QCursor& qc)
+                   Counters& cnt, QCursor& qc, bool& overflow)
 {
-    // stratum-major order: a wave traces the same stratum (x,y) of 64 neighbouring hits, whose
-    // rays leave nearby points in similar directions, instead of the 16 directions of 4 hits
     f3 o = F3(0, 0, 0), dir = F3(0, 0, 1);
-    Hit h = {}; float sh;
-    uint32_t dst = 0, sp = 0;
-    uint32_t slot = 0, k = 0;
+    Hit h; h.t = S.ambient.occlusion_dist; h.prim = H_MISS; h.u = 0; h.v = 0; h.rank = 0;
+    uint32_t dst = 0, sp = 0, slot = 0, k = 0, i = S.num_gates;
+    RayGate rg = {};
     if (valid) {   // slot = position of the path in this depth's path list; paths without AO rays hold no path id
-        // blocked stratum-major order: RT_AO_BLOCK consecutive slots x all n*n strata, stratum by
-        // stratum, so the 16 passes over a block's hit records (~70 B each) are served by L2
-        // item = base + off with base a multiple of 256 that is the same for the whole workgroup (GPU) and
-        // off < 256: block and stratum come from `base` alone, i.e. from scalar registers
-        const uint32_t n2b = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
-        const uint32_t nfull = nslots & ~(RT_AO_BLOCK - 1u);
-        if (base < nfull * n2b) {
-            const uint32_t b = base / (RT_AO_BLOCK * n2b), r = base % (RT_AO_BLOCK * n2b);
-            k = r / RT_AO_BLOCK; slot = b * RT_AO_BLOCK + (r & (RT_AO_BLOCK - 1u)) + off;
-        } else {
-            const uint32_t r = base + off - nfull * n2b, tail = nslots - nfull;
-            k = r / tail; slot = nfull + r % tail;
-        }
-    }
-    if (valid) {
+        ao_coords(S, nslots, base, off, slot, k);
         const q4 rw = B.ao_w[slot];
         valid = f2u(rw.w) != 0xFFFFFFFFu;
         if (valid) {
@@ -414,13 +460,46 @@ RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int dep
             cnt.rays++;
             o = xyz(ro);
             dir = ao_dir(S.ambient, xyz(ru), xyz(rw), f2u(ro.w), f2u(rw.w), k);
-            uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
-            dst = slot * n2 + k;
-            sp = trace<0, STATS, true>(S, o, dir, S.ambient.occlusion_dist, h, sh, st, cnt);
+            dst = slot * (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples) + k;
+            rg = make_gate(S.cull_pad, S.extent, o, dir);
+            i = (S.debug & 2u) ? S.num_gates : lead_planes_hit(S, o, dir, h);
         }
     }
-    if (defer_bvh<true, STATS>(S, B, C_BQA + depth, sp > 0, o, dir, h, dst, st, sp, cnt, qc)) return;
-    if (valid) B.ao_t[dst] = h.t;   // stays occlusion_dist when nothing closer was found
+    for (;;) {
+        if (i < S.num_gates) i = walk_gates<STATS>(S, o, dir, rg, i, h, st, sp, cnt);
+        const bool want = sp > 0;
+        const uint32_t item = chunk_append<RT_QCHUNK>(&B.counters[C_BQA + depth], want, qc, B.bq_roots, (uint32_t)REF_NONE, B.bq_cap);
+        if (want) {
+            if (item < B.bq_cap) {
+                const q4 a = {o.x, o.y, o.z, h.t};   // an upper bound of the ray's distance: the minimum is taken at the destination
+                const q4 b = {dir.x, dir.y, dir.z, u2f(dst | ((sp - 1u) << 29))};   // dst < 2^29 (checked where the batch is sized); 1 <= sp <= RT_DEFER_ROOTS
+                B.bq_a[item] = a; B.bq_b[item] = b;
+                for (uint32_t r = 0; r < sp; ++r) B.bq_roots[(size_t)r * B.bq_cap + item] = st.p[r * st.stride];
+            } else overflow = true;
+            sp = 0;
+        }
+        if (!wave_any(i < S.num_gates)) break;
+    }
+    if (valid) B.ao_key[dst] = t_key(h.t);   // stays occlusion_dist when nothing closer was found
+}
+
+// The rays of a wave of ao_item that found the queue full, each traversed in place, start to end (the queue is
+// sized so that this does not happen with the reference's scenes; tests force it).  `entry` = the wave's first item.
+template <bool STATS>
+RT_FN void ao_overflow_item(const DScene& S, const RenderArgs& A, const Batch& B, uint32_t entry, uint32_t lane, uint32_t nslots, Stack st, Counters& cnt)
+{
+    const uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
+    const uint32_t base = entry & ~255u, off = (entry & 255u) + lane;
+    if ((uint64_t)base + off >= (uint64_t)nslots * n2) return;
+    uint32_t slot, k;
+    ao_coords(S, nslots, base, off, slot, k);
+    const q4 rw = B.ao_w[slot];
+    if (f2u(rw.w) == 0xFFFFFFFFu) return;
+    const q4 ro = B.ao_o[slot], ru = B.ao_u[slot];
+    const f3 o = xyz(ro), dir = ao_dir(S.ambient, xyz(ru), xyz(rw), f2u(ro.w), f2u(rw.w), k);
+    Hit h; float sh;
+    trace<0, STATS, false>(S, o, dir, S.ambient.occlusion_dist, h, sh, st, cnt);
+    key_min(&B.ao_key[slot * n2 + k], t_key(h.t));
 }
 
 // world->ambient->L(sr): Light::L, or Ambient::L's reduction of the n*n distances in x,y order
@@ -435,14 +514,14 @@ RT_FN f3 ambient_L(const DScene& S, const Batch& B, uint32_t p)
     float dist = A.occlusion_dist;
     float maxSum = (dist * (float)n * (float)n);
     float occluded = maxSum;
-    const float* t = B.ao_t + (size_t)slot * n * n;
+    const uint32_t* t = B.ao_key + (size_t)slot * n * n;
     if (n == 4) {   // the reference's setting: four 16-byte loads in flight, then the same sequential sum
-        const q4* t4 = reinterpret_cast<const q4*>(t);   // slot * 16 floats: 64-byte aligned
+        const q4* t4 = reinterpret_cast<const q4*>(t);   // slot * 16 keys: 64-byte aligned
         const q4 a = t4[0], b = t4[1], c = t4[2], e = t4[3];
         const float v[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, e.x, e.y, e.z, e.w};
-        for (int k = 0; k < 16; ++k) occluded -= (dist - v[k]);
+        for (int k = 0; k < 16; ++k) occluded -= (dist - key_t(f2u(v[k])));
     } else {
-        for (unsigned k = 0; k < n * n; ++k) occluded -= (dist - t[k]);
+        for (unsigned k = 0; k < n * n; ++k) occluded -= (dist - key_t(t[k]));
     }
     float f = occluded / maxSum;
     return base * f * f;
@@ -573,10 +652,12 @@ void render_frame(Backend& be, RenderArgs A, uint32_t owned_tiles, uint32_t tile
         for (int d = 0; d < levels; ++d) {
             be.trace(A, d, paths);
             be.bvh_trace(A, d);
+            be.trace_overflow(A, d, paths);
             be.prep(A, d, paths);
             be.shadow(A, d);
             be.ao(A, d, paths);
             be.bvh_ao(A, d);
+            be.ao_overflow(A, d, paths);
             be.shade(A, d, paths);
         }
         be.resolve(A, A.npx);

@@ -90,7 +90,7 @@ int HostScene::validate()
     for (auto& r : scene) { int rc = ref_ok(r, false); if (rc) return rc; }
     for (auto& l : lights) if (l.kind != RT_LIGHT_POINT && l.kind != RT_LIGHT_DIRECTIONAL) return bad("light: unknown kind");
     if (ambient.occlusion_samples < 0 || ambient.occlusion_samples > 64) return bad("ambient: occlusion_samples out of range [0,64]");
-    if (triangles.size() >= (1u << 28)) { error = "more than 2^28 triangles"; return RT_ERR_UNSUPPORTED; }
+    if (triangles.size() >= (1u << 28) - 1u) { error = "more than 2^28 - 2 triangles"; return RT_ERR_UNSUPPORTED; }   // one slot is the builders' own
     return RT_OK;
 }
 
@@ -266,7 +266,7 @@ namespace {
 struct BuildTri { float mn[3], mx[3], c[3]; uint32_t gid; };
 // triangles per leaf: 2 (best of 1..8 measured on config 3: fewer exact tests outweigh the extra nodes); RT_LEAF_MAX overrides it for such measurements
 static const uint32_t kLeafMax = [] { const char* e = getenv("RT_LEAF_MAX"); int v = e ? atoi(e) : 2; return (uint32_t)(v < 1 ? 1 : v > 8 ? 8 : v); }();
-constexpr int kMaxDepth = 24;   // inner-node depth bound: RT_STACK_DEPTH (32) = RT_DEFER_ROOTS (8) pending roots + this
+constexpr int kMaxDepth = 24;   // inner-node depth bound of the two-wide tree: 25 levels = 13 four-wide levels (RT_STACK_DEPTH, rt_core.hpp)
 constexpr int kMaxBins = 64;
 // SAH bins per axis: RT_SAH_BINS overrides the default for measurements (8..64)
 static const int kBins = [] { const char* e = getenv("RT_SAH_BINS"); int v = e ? atoi(e) : 16; return v < 2 ? 2 : v > kMaxBins ? kMaxBins : v; }();
@@ -416,11 +416,10 @@ void HostScene::build_mesh_part(uint32_t mesh, int par, BvhPart& part) const
         for (auto& b : T) part.order.push_back(b.gid);
         const uint32_t leaf = REF_LEAF | ((m.num_triangles - 1u) << 28) | 0u;
         part.nodes.push_back({mn[0], mn[1], mn[2], mx[0]});
-        // every node has two valid children (the traversal does not test for absent ones): the second
-        // child is the same leaf behind a box that quantises to one grid point; entering it repeats a test, no more
+        // no second child: an inverted box and REF_NONE (collapse_node leaves the slots empty)
         part.nodes.push_back({mx[1], mx[2], INFINITY, INFINITY});
         part.nodes.push_back({INFINITY, -INFINITY, -INFINITY, -INFINITY});
-        part.nodes.push_back({u2f(leaf), u2f(leaf), 0.0f, 0.0f});
+        part.nodes.push_back({u2f(leaf), u2f((uint32_t)REF_NONE), 0.0f, 0.0f});
         part.root = 0;
     } else {
         part.root = build_subtree(T, 0, m.num_triangles, 0, par, part);
@@ -501,7 +500,8 @@ void HostScene::run_append_jobs()
     append_jobs_.clear();
 }
 
-// 64-byte float nodes -> 32-byte nodes: the 12 box coordinates become 16-bit grid indices in ONE frame
+// 64-byte float nodes -> 32-byte two-wide nodes -> 64-byte four-wide nodes (collapse_node, rt_core.hpp).
+// The 12 box coordinates become 16-bit grid indices in ONE frame
 // for the whole scene (qbase + q * qscale), rounded outwards by a full grid step beyond floor/ceil, so
 // the decoded box always contains the float box (checked below with the decode arithmetic of
 // cull_box's callers); the traversal's padded slab test then works on a superset, which culling allows.
@@ -530,7 +530,7 @@ void HostScene::quantize_nodes()
         qbase[a] = mn[a];
         qscale[a] = std::max((mx[a] - mn[a]) / 65533.0f, 1e-30f);
     }
-    nodes4.assign(n * 2, q4{0, 0, 0, 0});
+    std::vector<q4> nodes2(n * 2, q4{0, 0, 0, 0});   // quantised two-wide nodes: the input of collapse_node()
     parallel_ranges(n, 1 << 16, [&](size_t b, size_t e) {
     for (size_t i = b; i < e; ++i) {
         uint32_t q[12] = {0};
@@ -549,9 +549,18 @@ void HostScene::quantize_nodes()
         }
         uint32_t w[6];
         for (int k = 0; k < 6; ++k) w[k] = q[2 * k] | (q[2 * k + 1] << 16);
-        nodes4[i * 2 + 0] = {u2f(w[0]), u2f(w[1]), u2f(w[2]), u2f(w[3])};
-        nodes4[i * 2 + 1] = {u2f(w[4]), u2f(w[5]), fnodes4[i * 4 + 3].x, fnodes4[i * 4 + 3].y};
+        nodes2[i * 2 + 0] = {u2f(w[0]), u2f(w[1]), u2f(w[2]), u2f(w[3])};
+        nodes2[i * 2 + 1] = {u2f(w[4]), u2f(w[5]), fnodes4[i * 4 + 3].x, fnodes4[i * 4 + 3].y};
     }
+    });
+    // four-wide nodes, same indices (a Mesh's root keeps its index; nodes on odd levels go unused); their unused
+    // slots refer to one degenerate triangle appended behind the last slot (collapse_node, rt_core.hpp)
+    const uint32_t null_slot = (uint32_t)(tris4.size() / 3);
+    tris4.resize(tris4.size() + 3, q4{0, 0, 0, 0});
+    const uint32_t empty_ref = REF_LEAF | null_slot;
+    nodes4.assign(n * 4, q4{0, 0, 0, 0});
+    parallel_ranges(n, 1 << 16, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) collapse_node(nodes2.data(), (uint32_t)i, empty_ref, &nodes4[i * 4]);
     });
 }
 
@@ -778,7 +787,7 @@ int HostScene::build()
             qbase[a] = mn[a];
             qscale[a] = std::max((mx[a] - mn[a]) / 65533.0f, 1e-30f);
         }
-        if ((uint64_t)gpu_slots >= (1ull << 28)) { error = "too many triangle slots for a leaf reference"; return RT_ERR_UNSUPPORTED; }
+        if ((uint64_t)gpu_slots >= (1ull << 28) - 1u) { error = "too many triangle slots for a leaf reference"; return RT_ERR_UNSUPPORTED; }
     } else
     quantize_nodes();
     mesh_part_.clear(); mesh_part_.shrink_to_fit();

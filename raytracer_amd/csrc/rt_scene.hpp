@@ -33,7 +33,7 @@ struct HostScene {
     // ---- flattened form (what gets uploaded) ----
     std::vector<GateNode> gates;
     std::vector<q4> planes4, spheres4, tris4, attr4, nodes4;
-    std::vector<q4> fnodes4;            // build-time float nodes (4 q4 each); nodes4 holds the quantised 2-q4 nodes
+    std::vector<q4> fnodes4;            // build-time float nodes (4 q4 each, two-wide); nodes4 holds the quantised four-wide nodes (4 q4 each)
     float qbase[3] = {0, 0, 0}, qscale[3] = {1, 1, 1};   // node grid: coordinate = qbase + q * qscale
     std::vector<DMaterial> dmaterials;
     std::vector<DLight> dlights;

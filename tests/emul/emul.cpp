@@ -26,7 +26,15 @@ struct LoopBackend {
     void trace(const RenderArgs& A, int d, uint32_t fixed) {
         Stack st{stack.data(), 1};
         QCursor qc{0, 0};
-        for (uint32_t i = 0, n = count(d, fixed); i < n; ++i) trace_item<true>(S, A, B, d, i, true, st, cnt[0], qc);
+        for (uint32_t i = 0, n = count(d, fixed); i < n; ++i) {
+            bool overflow = false;
+            trace_item<true>(S, A, B, d, i, true, st, cnt[0], qc, overflow);
+            if (overflow) B.ao_ovf[B.counters[C_TR_OVF + d]++] = i;   // a "wave" of one lane
+        }
+    }
+    void trace_overflow(const RenderArgs& A, int d, uint32_t fixed) {
+        Stack st{stack.data(), 1};
+        for (uint32_t e = 0; e < B.counters[C_TR_OVF + d]; ++e) trace_overflow_item<true>(S, A, B, d, B.ao_ovf[e], 0, count(d, fixed), st, cnt[0]);
     }
     void bvh_trace(const RenderArgs& A, int d) {
         Stack st{stack.data(), 1};
@@ -46,7 +54,16 @@ struct LoopBackend {
         uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
         QCursor qc{0, 0};
         const uint32_t nslots = count(d, fixed);
-        for (uint32_t i = 0, n = nslots * n2; i < n; ++i) ao_item<true>(S, A, B, d, i & ~255u, i & 255u, nslots, true, st, cnt[2], qc);
+        for (uint32_t i = 0, n = nslots * n2; i < n; ++i) {
+            bool overflow = false;
+            ao_item<true>(S, A, B, d, i & ~255u, i & 255u, nslots, true, st, cnt[2], qc, overflow);
+            if (overflow) B.ao_ovf[B.counters[C_AO + d]++] = i;   // a "wave" of one lane
+        }
+    }
+    void ao_overflow(const RenderArgs& A, int d, uint32_t fixed) {
+        Stack st{stack.data(), 1};
+        const uint32_t nslots = count(d, fixed);
+        for (uint32_t e = 0; e < B.counters[C_AO + d]; ++e) ao_overflow_item<true>(S, A, B, B.ao_ovf[e], 0, nslots, st, cnt[2]);
     }
     void shade(const RenderArgs& A, int d, uint32_t fixed) { for (uint32_t i = 0, n = count(d, fixed); i < n; ++i) shade_item(S, A, B, d, i); }
     void resolve(const RenderArgs& A, uint32_t n) {
@@ -115,7 +132,8 @@ int emul_render(const rt_scene_desc* d, const rt_camera* cam, const rt_params* p
     B.P = P;
     std::vector<q4> ro0(P), ro1(P), rd0(P), rd1(P), hit(P), nrm(P), lvl((size_t)P * A.levels);
     std::vector<uint32_t> pstate(P), q0(P), q1(P), aos(P), shq((size_t)P * nl), counters(C_TOTAL);
-    std::vector<float> aot((size_t)P * (n2 ? n2 : 1)), shr((size_t)P * nl), lph((size_t)P * A.levels * (nl > 1 ? nl - 1 : 1));
+    std::vector<uint32_t> aot((size_t)P * (n2 ? n2 : 1)), aovf((size_t)P * (n2 ? n2 : 1));
+    std::vector<float> shr((size_t)P * nl), lph((size_t)P * A.levels * (nl > 1 ? nl - 1 : 1));
     std::vector<uint8_t> kind((size_t)P * A.levels);
     std::vector<unsigned long long> stats(ST_TOTAL, 0);
     // a deliberately small queue so the inline fallback of defer_bvh is exercised too
@@ -127,7 +145,7 @@ int emul_render(const rt_scene_desc* d, const rt_camera* cam, const rt_params* p
     B.bq_a = bqa.data(); B.bq_b = bqb.data(); B.bq_c = bqc.data(); B.bq_roots = bqr.data();
     B.ray_o[0] = ro0.data(); B.ray_o[1] = ro1.data(); B.ray_d[0] = rd0.data(); B.ray_d[1] = rd1.data();
     B.hit = hit.data(); B.nrm = nrm.data(); B.pstate = pstate.data(); B.queue[0] = q0.data(); B.queue[1] = q1.data();
-    B.ao_o = aoo.data(); B.ao_u = aou.data(); B.ao_w = aow.data(); B.ao_slot = aos.data(); B.sh_queue = shq.data(); B.ao_t = aot.data(); B.sh_res = shr.data();
+    B.ao_o = aoo.data(); B.ao_u = aou.data(); B.ao_w = aow.data(); B.ao_slot = aos.data(); B.sh_queue = shq.data(); B.ao_key = aot.data(); B.ao_ovf = aovf.data(); B.ovf_cap = (uint32_t)aovf.size(); B.sh_res = shr.data();
     B.lvl = lvl.data(); B.lvl_ph = lph.data(); B.lvl_kind = kind.data(); B.counters = counters.data(); B.stats = stats.data();
     render_frame(be, A, owned, tiles_per_batch, H.has_bounce_materials);
     if (out_counts) {
