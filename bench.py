@@ -26,16 +26,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--spp", type=int, default=16)
+    ap.add_argument("--config", type=int, default=3, choices=(3, 5),
+                    help="BASELINE.json config: 3 (default, the headline: 4K, 16 spp + AO16, one textured BVH mesh) or 5 (10.2 M "
+                         "triangles in 2500 instanced meshes behind the reference's shape-level BVH; default size 1920x1080, 4 spp)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--instances", type=int, default=2500, help="config 5: instanced meshes of 4096 triangles")
     ap.add_argument("--mesh-nu", type=int, default=700)
     ap.add_argument("--mesh-nv", type=int, default=360)
     ap.add_argument("--lib", default=None, help="alternative librt_amd.so (kernel tuning builds)")
     ap.add_argument("--batch-paths", type=int, default=0, help="paths per wavefront batch (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL over xGMI) or gloo (rehearsal: ranks may share one GPU, slabs staged through the host)")
-    ap.add_argument("--cpu-crop", type=int, default=96, help="edge of the centre crop timed on the CPU")
+    ap.add_argument("--cpu-crop", type=int, default=None, help="edge of the centre crop timed on the CPU (default 96; config 5: 24)")
+    ap.add_argument("--cpu-baseline", action="store_true", help="config 5 only: time the reference too (it builds 10 M Triangle objects: ~1 min, ~3 GB)")
     args = ap.parse_args()
 
     import numpy as np
@@ -61,7 +66,12 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    world = scenes.config3_scene(args.width, args.height, args.spp, args.mesh_nu, args.mesh_nv)
+    if args.config == 3:
+        args.width, args.height, args.spp = args.width or 3840, args.height or 2160, args.spp or 16
+        world = scenes.config3_scene(args.width, args.height, args.spp, args.mesh_nu, args.mesh_nv)
+    else:
+        args.width, args.height, args.spp = args.width or 1920, args.height or 1080, args.spp or 4
+        world = scenes.config5_scene(args.width, args.height, args.spp, instances=args.instances)
     flat = world.flatten()
     ntri = int(flat.arrays["triangles"].shape[0])
     r = Renderer(gpu_index, args.lib)
@@ -133,56 +143,71 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = rays_total / (ms_per_step * 1e-3) / 1e6
-        # roofline of the dominant kernel = the compacted triangle-BVH traversal of the ambient-
-        # occlusion rays (k_bvh<AO>), rank 0's launches.  Algorithmic bytes per ray it processes:
-        # B = 96 + 32*V + 48*T (SURVEY.md 8d's formula with this build's node size: ray+hit records,
-        # V 32-byte quantised nodes, T 48-byte triangles; V and T come from the counting pass and
-        # count cache hits too).
-        k = capi.RT_K_NAMES.index("ao_bvh")
-        units = float(st_count.bvh_rays[2])
-        V = st_count.nodes[2] / max(1.0, units)
-        T = st_count.tris[2] / max(1.0, units)
-        b_ray = 96.0 + 32.0 * V + 48.0 * T
-        k_ms = kernel_ms[k] / args.steps
-        k_launches = launches[k] / args.steps
-        achieved = (units * b_ray) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic = None
+        traffic_all = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_bvh_ao_bytes_per_launch")
+                traffic_all = json.load(open(tpath)).get(f"config{args.config}", {})
             except Exception:
-                traffic = None
+                traffic_all = {}
         ao_rays = float(st_count.rays_ao)
+        if args.config == 3:
+            # roofline of the dominant kernel = the compacted triangle-BVH traversal of the ambient-occlusion rays
+            # (k_bvh<AO>), rank 0's launches.  Algorithmic bytes per ray it processes: B = 96 + 64*V + 48*T (SURVEY.md
+            # 8d: ray + hit records, V 64-byte four-wide nodes, T 48-byte triangles; V and T come from the counting pass
+            # and count cache hits too).
+            kname, k = "k_bvh<AO>", capi.RT_K_NAMES.index("ao_bvh")
+            units = float(st_count.bvh_rays[2])
+            V = st_count.nodes[2] / max(1.0, units)
+            T = st_count.tris[2] / max(1.0, units)
+            b_ray = 96.0 + 64.0 * V + 48.0 * T
+            extra = {"nodes_per_ray": round(V, 2), "tris_per_ray": round(T, 2), "ao_rays_total": int(ao_rays), "ao_rays_needing_bvh": int(units)}
+            limiter = "valu-issue, then cache-served gathers (working set in L2/MALL; see profiles/*_pmc.csv and DESIGN.md 4)"
+        else:
+            # config 5: the gate walk of the AO rays (k_ao) dominates: per ray the 48-byte AO frame, G 48-byte gate
+            # nodes of the reference's shape-level hierarchy (G from the counting pass, LDS-staged ones included),
+            # one 64-byte queue item per ray that reaches a mesh, 4 bytes of result.
+            kname, k = "k_ao", capi.RT_K_NAMES.index("ao")
+            units = ao_rays
+            G = st_count.gates[2] / max(1.0, units)
+            share = st_count.bvh_rays[2] / max(1.0, units)
+            b_ray = 48.0 + 48.0 * G + 64.0 * share + 4.0
+            extra = {"gates_per_ray": round(G, 2), "queued_share": round(share, 3), "ao_rays_total": int(ao_rays)}
+            limiter = "dependent 48-byte gate-node gathers + exact box tests (latency / VALU), not HBM"
+        k_ms = kernel_ms[k] / args.steps
+        k_launches = launches[k] / args.steps / (2.0 if k == capi.RT_K_NAMES.index("ao") else 1.0)   # the 'ao' class also times the (empty) overflow launch
+        achieved = (units * b_ray) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic = traffic_all.get("bytes_per_launch")
         launch_s = (k_ms / max(1.0, k_launches)) * 1e-3
         # `achieved` / `frac` are ALGORITHMIC bytes (cache hits count) over the launch time, as SURVEY 8d defines them;
         # `traffic` is what the HBM counters saw per launch (profiles/traffic.json, separate rocprofv3 --pmc passes) and
-        # `traffic_gbs` / `traffic_frac` the HBM rate that corresponds to.  The kernel's working set sits in L2 / MALL,
-        # so it is the VALU issue rate, not HBM, that limits it: `limiter` says so.
+        # `traffic_gbs` / `traffic_frac` the HBM rate that corresponds to.  `limiter` names what actually binds.
         roofline = {
-            "bound": "hbm", "kernel": "k_bvh<AO>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "traffic_gbs": round(traffic / launch_s / 1e9, 1) if traffic and launch_s > 0 else None,
             "traffic_frac": round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic and launch_s > 0 else None,
-            "limiter": "valu-issue (working set served by L2/MALL; see profiles/*_pmc.csv)",
-            "bytes_per_ray": round(b_ray, 1), "nodes_per_ray": round(V, 2), "tris_per_ray": round(T, 2),
+            "limiter": limiter, "bytes_per_ray": round(b_ray, 1),
             "rays_per_launch": round(units / max(1.0, k_launches), 1), "avg_launch_ms": round(k_ms / max(1.0, k_launches), 4),
             "mrays_per_s_in_kernel": round(units / (k_ms * 1e-3) / 1e6, 1) if k_ms > 0 else None,
-            "ao_rays_total": int(ao_rays), "ao_rays_needing_bvh": int(units),
         }
+        roofline.update(extra)
         torch.cuda.synchronize()
         checksum = int(frame.view(torch.int32).to(torch.int64).sum().item()) & 0xFFFFFFFFFFFFFFFF   # same for every N
         line = {
             "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world_size,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"config3: {W}x{H}, {args.spp} jittered spp + 4x4 ambient occlusion, room + textured "
-                                   f"{ntri}-triangle BVH mesh, 1 point light", "rays_per_frame": int(rays_total), "frame_checksum": checksum,
+            "config": {"workload": (f"config3: {W}x{H}, {args.spp} jittered spp + 4x4 ambient occlusion, room + textured "
+                                    f"{ntri}-triangle BVH mesh, 1 point light") if args.config == 3 else
+                                   (f"config5: {W}x{H}, {args.spp} jittered spp + 4x4 ambient occlusion, room + {args.instances} instanced "
+                                    f"meshes = {ntri} triangles behind the reference's shape-level BVH, 1 point light"),
+                       "rays_per_frame": int(rays_total), "frame_checksum": checksum,
                        "parallelism": f"tiles64 x {world_size} gpu"},
             "kernel_ms_per_step": {n: round(float(kernel_ms[i]) / args.steps, 3) for i, n in enumerate(capi.RT_K_NAMES)},
             "roofline": roofline,
         }
-        if world_size == 1 and not args.no_cpu_baseline:
+        if world_size == 1 and not args.no_cpu_baseline and (args.config == 3 or args.cpu_baseline):
             line["cpu_baseline"] = cpu_baseline(world, flat, args)
         print(json.dumps(line), flush=True)
     r.close()
@@ -205,7 +230,7 @@ def cpu_baseline(world, flat, args):
         orc, kind = bindings.RefOracle(), "reference"
     else:
         orc, kind = bindings.PortOracle(), "port"
-    c = args.cpu_crop
+    c = args.cpu_crop or (96 if args.config == 3 else 24)
     p = world.params(seed=1)
     p.num_samples = 1
     p.x0, p.x1 = args.width // 2 - c // 2, args.width // 2 - c // 2 + c

@@ -14,6 +14,8 @@ import pandas as pd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+config = sys.argv[2] if len(sys.argv) > 2 else "config3"                  # key in profiles/traffic.json
+dominant = sys.argv[3] if len(sys.argv) > 3 else "k_bvh<true, false>"     # the kernel bench.py's roofline is about
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
@@ -54,18 +56,28 @@ if rows:
     allc.to_csv(os.path.join(P, f"{tag}_pmc.csv"), index=False)
     piv = allc.pivot_table(index="k", columns="Counter_Name", values="per_launch")
     print(piv.to_string())
-    k = "k_bvh<true, false>"
+    k = dominant
     if k in piv.index and "FETCH_SIZE" in piv.columns:
         fetch_kib = float(piv.loc[k, "FETCH_SIZE"])
         write_kib = float(piv.loc[k, "WRITE_SIZE"]) if "WRITE_SIZE" in piv.columns else 0.0
         out = {
             "kernel": k, "tag": tag,
             "fetch_bytes_per_launch_raw": fetch_kib * 1024, "write_bytes_per_launch": write_kib * 1024,
-            "k_bvh_ao_bytes_per_launch": fetch_kib * 1024 + write_kib * 1024,
-            "k_bvh_ao_bytes_per_launch_if_fetch_doubled": 2 * fetch_kib * 1024 + write_kib * 1024,
+            "bytes_per_launch": fetch_kib * 1024 + write_kib * 1024,
+            "bytes_per_launch_if_fetch_doubled": 2 * fetch_kib * 1024 + write_kib * 1024,
             "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB -> bytes, averaged over the "
                     "launches of one frame (steps 1, warmup 1); raw FETCH_SIZE used (scattered 16-B gathers, not the "
                     "wide coalesced stream for which gfx950 under-reports by 2x)",
         }
-        json.dump(out, open(os.path.join(P, "traffic.json"), "w"), indent=1)
+        path = os.path.join(P, "traffic.json")
+        allt = {}
+        if os.path.exists(path):
+            try:
+                allt = json.load(open(path))
+            except Exception:
+                allt = {}
+        if "kernel" in allt:   # round-1 layout: one record
+            allt = {"config3_r01": allt}
+        allt[config] = out
+        json.dump(allt, open(path, "w"), indent=1)
         print(json.dumps(out, indent=1))
