@@ -252,6 +252,19 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* p,
 int rt_render_device_noalloc(rt_scene* s, const rt_camera* cam, const rt_params* p,
                              float* d_rgb, uint32_t* d_primid, float* d_t, void* stream);
 
+/* Multi-GPU render from ONE process (the C++ drop-in's ThreadPool::waitDone, main.cpp:1809-1827: the reference's
+ * pool threads become GPUs).  scenes[0..num_scenes) hold the SAME committed scene description, each on a context
+ * of its own (normally one per GPU: rt_init(i)); rank i renders the RT_TILE tiles t with t % num_scenes == i on
+ * its context's stream from a host thread of its own, sends its compact slab to scenes[0]'s GPU (one peer copy
+ * per rank: each peer has its own xGMI link to GPU 0), where the slabs are scattered into the frame
+ * (rt_unpack_tiles' kernel) and copied to `rgb` (host, width*height*3 floats; pixels outside the render rectangle
+ * are left untouched).  The frame is bit-identical to a single rt_render.  p->tile_rank / tile_world are
+ * ignored.  stats: NULL or num_scenes records (one per rank).  Contexts may share a device (how the tests run it
+ * on a one-GPU box).  The torch.distributed path of bench.py (one process per GPU, RCCL gather) is the
+ * alternative for Python hosts. */
+int rt_render_multi(rt_scene* const* scenes, int num_scenes, const rt_camera* cam, const rt_params* p,
+                    float* rgb, rt_stats* stats);
+
 /* Number of RT_TILE tiles of the render rectangle owned by (rank, world). */
 int rt_owned_tiles(const rt_params* p, int rank, int world, uint32_t* out);
 

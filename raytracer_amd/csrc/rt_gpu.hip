@@ -16,6 +16,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_kernels.hpp"
@@ -264,6 +265,9 @@ struct rt_ctx {
     unsigned long long* d_stats = nullptr;
     uint32_t* d_counters = nullptr;
     float* d_rgb = nullptr; uint32_t* d_prim = nullptr; float* d_t = nullptr; size_t out_pixels = 0;
+    // rt_render_multi: this context's tile slab, and (on the gathering context) the slabs of all ranks
+    float* d_slab = nullptr; size_t slab_floats = 0;
+    float* d_gather = nullptr; size_t gather_floats = 0;
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     // Stream ordering.  ev_done: end of the last piece of work that used the context's shared buffers (batch
@@ -545,6 +549,7 @@ int rt_shutdown(rt_ctx* c)
     if (c->ev_null) (void)hipEventDestroy(c->ev_null);
     (void)hipFree(c->batch_mem); (void)hipFree(c->d_stats); (void)hipFree(c->d_counters);
     (void)hipFree(c->d_rgb); (void)hipFree(c->d_prim); (void)hipFree(c->d_t);
+    (void)hipFree(c->d_slab); (void)hipFree(c->d_gather);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return RT_OK;
@@ -1002,6 +1007,118 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* p, float* rgb,
     if (rgb) HIPCHECK(ctx, hipMemcpy(rgb, ctx->d_rgb, npix * 12, hipMemcpyDeviceToHost));
     if (primid) HIPCHECK(ctx, hipMemcpy(primid, ctx->d_prim, npix * 4, hipMemcpyDeviceToHost));
     if (t) HIPCHECK(ctx, hipMemcpy(t, ctx->d_t, npix * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// grows one of a context's cached device buffers (the context's device is current, its mutex held)
+static int ensure_floats(rt_ctx* ctx, float** buf, size_t* have, size_t need)
+{
+    if (need <= *have) return RT_OK;
+    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (*buf) HIPCHECK(ctx, hipFree(*buf));
+    *buf = nullptr; *have = 0;
+    HIPCHECK(ctx, hipMalloc((void**)buf, need * sizeof(float)));
+    *have = need;
+    return RT_OK;
+}
+
+int rt_render_multi(rt_scene* const* scenes, int num_scenes, const rt_camera* cam, const rt_params* p, float* rgb, rt_stats* stats)
+{
+    if (!scenes || num_scenes < 1 || !cam || !p || !rgb) return RT_ERR_INVALID;
+    for (int i = 0; i < num_scenes; ++i) if (!scenes[i]) return RT_ERR_INVALID;
+    rt_ctx* ctx0 = scenes[0]->ctx;
+    if (num_scenes == 1) {
+        rt_params q = *p;
+        q.tile_rank = 0; q.tile_world = 1;
+        return rt_render(scenes[0], cam, &q, rgb, nullptr, nullptr, stats);
+    }
+    for (int i = 0; i < num_scenes; ++i)
+        for (int j = 0; j < i; ++j)
+            if (scenes[i]->ctx == scenes[j]->ctx) { ctx0->error = "rt_render_multi: every scene needs a context of its own"; return RT_ERR_INVALID; }
+    rt_params base = *p;
+    base.tile_rank = 0; base.tile_world = num_scenes;
+    {
+        std::lock_guard<std::mutex> lk(ctx0->mu);
+        int rc = check_params(ctx0, &base);
+        if (rc) return rc;
+    }
+    // slab layout of every rank: [owned tiles][RT_TILE*RT_TILE][3]; rank 0 owns the most tiles
+    uint32_t max_owned = 0;
+    rt_owned_tiles(&base, 0, num_scenes, &max_owned);
+    const size_t slab_floats = (size_t)max_owned * RT_TILE * RT_TILE * 3;
+    const size_t npix = (size_t)p->width * p->height;
+    {
+        std::lock_guard<std::mutex> lk(ctx0->mu);
+        HIPCHECK(ctx0, hipSetDevice(ctx0->device));
+        int rc = ensure_floats(ctx0, &ctx0->d_gather, &ctx0->gather_floats, slab_floats * (size_t)num_scenes);
+        if (rc) return rc;
+        if (npix > ctx0->out_pixels) {
+            HIPCHECK(ctx0, hipStreamSynchronize(ctx0->stream));
+            (void)hipFree(ctx0->d_rgb); (void)hipFree(ctx0->d_prim); (void)hipFree(ctx0->d_t);
+            ctx0->d_rgb = nullptr; ctx0->d_prim = nullptr; ctx0->d_t = nullptr; ctx0->out_pixels = 0;
+            HIPCHECK(ctx0, hipMalloc((void**)&ctx0->d_rgb, npix * 12));
+            HIPCHECK(ctx0, hipMalloc((void**)&ctx0->d_prim, npix * 4));
+            HIPCHECK(ctx0, hipMalloc((void**)&ctx0->d_t, npix * 4));
+            ctx0->out_pixels = npix;
+        }
+    }
+    // one host thread + the context's own stream per rank: render the rank's tiles, send the slab to the gathering GPU
+    std::vector<int> rcs((size_t)num_scenes, RT_OK);
+    auto rank_work = [&](int i) -> int {
+        rt_scene* s = scenes[i];
+        rt_ctx* ctx = s->ctx;
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (!s->committed) { ctx->error = "rt_render_multi: scene not committed"; return RT_ERR_STATE; }
+        HIPCHECK(ctx, hipSetDevice(ctx->device));
+        uint32_t owned = 0;
+        rt_owned_tiles(&base, i, num_scenes, &owned);
+        if (owned == 0) { if (stats) std::memset(&stats[i], 0, sizeof(rt_stats)); return RT_OK; }
+        int rc = ensure_floats(ctx, &ctx->d_slab, &ctx->slab_floats, slab_floats);
+        if (rc) return rc;
+        rt_params q = base;
+        q.tile_rank = i;
+        rc = render_locked(s, cam, &q, ctx->d_slab, nullptr, nullptr, stats ? &stats[i] : nullptr, ctx->stream, true, false);
+        if (rc) return rc;
+        const size_t bytes = (size_t)owned * RT_TILE * RT_TILE * 3 * sizeof(float);
+        float* dst = ctx0->d_gather + slab_floats * (size_t)i;
+        if (ctx->device == ctx0->device) HIPCHECK(ctx, hipMemcpyAsync(dst, ctx->d_slab, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        else HIPCHECK(ctx, hipMemcpyPeerAsync(dst, ctx0->device, ctx->d_slab, ctx->device, bytes, ctx->stream));   // one xGMI link per peer, all ranks at once
+        HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+        return RT_OK;
+    };
+    {
+        std::vector<std::thread> threads;
+        for (int i = 1; i < num_scenes; ++i) threads.emplace_back([&, i] { rcs[(size_t)i] = rank_work(i); });
+        rcs[0] = rank_work(0);
+        for (auto& t : threads) t.join();
+    }
+    for (int i = 0; i < num_scenes; ++i)
+        if (rcs[(size_t)i] != RT_OK) {
+            if (i != 0) ctx0->error = "rt_render_multi: rank " + std::to_string(i) + ": " + scenes[i]->ctx->error;
+            return rcs[(size_t)i];
+        }
+    // scatter the slabs into the frame on the gathering GPU and hand the frame to the caller
+    std::lock_guard<std::mutex> lk(ctx0->mu);
+    HIPCHECK(ctx0, hipSetDevice(ctx0->device));
+    const bool rect = p->x0 != 0 || p->y0 != 0 || p->x1 != p->width || p->y1 != p->height;
+    uint32_t tx, ty;
+    tile_grid(&base, tx, ty);
+    for (int i = 0; i < num_scenes; ++i) {
+        uint32_t owned = 0;
+        rt_owned_tiles(&base, i, num_scenes, &owned);
+        if (owned == 0) continue;
+        hipLaunchKernelGGL(k_unpack, dim3(grid_for((uint64_t)owned * RT_TILE * RT_TILE)), dim3(RT_BLOCK), 0, ctx0->stream,
+                           ctx0->d_gather + slab_floats * (size_t)i, ctx0->d_rgb, p->width, p->x0, p->y0, p->x1, p->y1, tx, ty, i, num_scenes, owned);
+    }
+    HIPCHECK(ctx0, hipGetLastError());
+    HIPCHECK(ctx0, hipStreamSynchronize(ctx0->stream));
+    if (rect) {   // raytrace(beginY,endY,beginX,endX): only the rectangle travels back
+        const size_t w = (size_t)(p->x1 - p->x0), h = (size_t)(p->y1 - p->y0), W = (size_t)p->width;
+        const size_t first = (size_t)p->y0 * W + (size_t)p->x0;
+        if (w && h) HIPCHECK(ctx0, hipMemcpy2D(rgb + first * 3, W * 12, ctx0->d_rgb + first * 3, W * 12, w * 12, h, hipMemcpyDeviceToHost));
+        return RT_OK;
+    }
+    HIPCHECK(ctx0, hipMemcpy(rgb, ctx0->d_rgb, npix * 12, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -88,19 +88,45 @@ struct Flat {
     }
 };
 
-struct Gpu {   // one context + the uploaded scene of the World last rendered
-    rt_ctx* ctx = nullptr; rt_scene* scene = nullptr;
+// The GPUs of this process: one context (+ the uploaded scene of the World last rendered) per device of the
+// list.  RT_GPU_DEVICES="0,1,2,3" names the devices (a device may appear more than once: contexts then share
+// it, which is how the tests run the multi-GPU path on a one-GPU box); RT_NUM_GPUS=N means devices 0..N-1;
+// default: device 0.  With more than one context a frame is rendered by rt_render_multi: tiles t % N == i on
+// context i, slabs gathered on the first device (the reference's pool threads, main.cpp:1803-1827, become GPUs).
+struct Gpu {
+    std::vector<rt_ctx*> ctx; std::vector<rt_scene*> scene;
     const World* world = nullptr; unsigned long revision = ~0ul;
     std::mutex mu;
-    ~Gpu() { if (scene) rt_scene_destroy(scene); if (ctx) rt_shutdown(ctx); }
+    ~Gpu() { for (auto s : scene) if (s) rt_scene_destroy(s); for (auto c : ctx) if (c) rt_shutdown(c); }
 };
 Gpu& gpu() { static Gpu g; return g; }
 
+std::vector<int> device_list()
+{
+    std::vector<int> d;
+    if (const char* e = std::getenv("RT_GPU_DEVICES")) {
+        std::istringstream ss(e);
+        std::string tok;
+        while (std::getline(ss, tok, ',')) if (!tok.empty()) d.push_back(std::atoi(tok.c_str()));
+    } else if (const char* n = std::getenv("RT_NUM_GPUS")) {
+        for (int i = 0; i < std::max(1, std::atoi(n)); ++i) d.push_back(i);
+    }
+    if (d.empty()) d.push_back(0);
+    return d;
+}
+
 void ensure_uploaded(Gpu& g, const World& w)
 {
-    if (!g.ctx && rt_init(0, &g.ctx) != RT_OK) fail("rt_init");
-    if (g.world == &w && g.revision == w.mRevision && g.scene) return;
-    if (g.scene) { rt_scene_destroy(g.scene); g.scene = nullptr; }
+    if (g.ctx.empty()) {
+        for (int dev : device_list()) {
+            rt_ctx* c = nullptr;
+            if (rt_init(dev, &c) != RT_OK) fail("rt_init(" + std::to_string(dev) + ")");
+            g.ctx.push_back(c);
+        }
+        g.scene.assign(g.ctx.size(), nullptr);
+    }
+    if (g.world == &w && g.revision == w.mRevision && g.scene[0]) return;
+    for (auto& s : g.scene) if (s) { rt_scene_destroy(s); s = nullptr; }
     Flat f;
     for (auto& s : w.scene) f.scene.push_back(f.ref_of(s));
     for (auto& l : w.lights) f.lights.push_back(rt_light{l->mKind, {l->mV.x, l->mV.y, l->mV.z}, {l->mColour.x, l->mColour.y, l->mColour.z}, l->mRadiance});
@@ -119,9 +145,18 @@ void ensure_uploaded(Gpu& g, const World& w)
     d.textures = f.textures.data(); d.num_textures = (uint32_t)f.textures.size();
     d.lights = f.lights.data(); d.num_lights = (uint32_t)f.lights.size();
     d.ambient = f.ambient;
-    if (rt_scene_create(g.ctx, &g.scene) != RT_OK) fail("rt_scene_create", g.ctx);
-    if (rt_scene_set_desc(g.scene, &d) != RT_OK) fail("rt_scene_set_desc", g.ctx);
-    if (rt_scene_commit(g.scene) != RT_OK) fail("rt_scene_commit", g.ctx);
+    // the scene is replicated: every context gets its own copy (commits run side by side)
+    std::vector<std::string> errs(g.ctx.size());
+    auto upload = [&](size_t i) {
+        if (rt_scene_create(g.ctx[i], &g.scene[i]) != RT_OK) { errs[i] = std::string("rt_scene_create: ") + rt_last_error(g.ctx[i]); return; }
+        if (rt_scene_set_desc(g.scene[i], &d) != RT_OK) { errs[i] = std::string("rt_scene_set_desc: ") + rt_last_error(g.ctx[i]); return; }
+        if (rt_scene_commit(g.scene[i]) != RT_OK) errs[i] = std::string("rt_scene_commit: ") + rt_last_error(g.ctx[i]);
+    };
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < g.ctx.size(); ++i) th.emplace_back(upload, i);
+    upload(0);
+    for (auto& t : th) t.join();
+    for (auto& e : errs) if (!e.empty()) throw std::runtime_error(e);
     g.world = &w; g.revision = w.mRevision;
 }
 
@@ -139,7 +174,14 @@ void render_rect(int y0, int y1, int x0, int x1, rt_camera cam, std::shared_ptr<
     p.max_depth = world->maxDepth; p.light_attenuation = (float)lightAttenuationFactor; p.seed = world->seed;
     if (stats) p.flags = RT_FLAG_TIMING;
     static_assert(sizeof(Colour) == 3 * sizeof(float), "Colour must be three packed floats");
-    if (rt_render(g.scene, &cam, &p, reinterpret_cast<float*>(world->image.data()), nullptr, nullptr, stats) != RT_OK) fail("rt_render", g.ctx);
+    float* image = reinterpret_cast<float*>(world->image.data());
+    if (g.ctx.size() == 1) {
+        if (rt_render(g.scene[0], &cam, &p, image, nullptr, nullptr, stats) != RT_OK) fail("rt_render", g.ctx[0]);
+    } else {
+        std::vector<rt_stats> per(g.ctx.size());
+        if (rt_render_multi(g.scene.data(), (int)g.scene.size(), &cam, &p, image, stats ? per.data() : nullptr) != RT_OK) fail("rt_render_multi", g.ctx[0]);
+        if (stats) *stats = per[0];   // rank 0's record (ray counts are per rank)
+    }
 }
 
 } // namespace

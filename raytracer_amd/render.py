@@ -98,6 +98,21 @@ class Renderer:
         rc = self.lib.rt_render_device_noalloc(self.scene, C.byref(cam), C.byref(params), d_rgb, d_prim, d_t, stream)
         self._check(rc, "rt_render_device_noalloc")
 
+    @staticmethod
+    def render_multi(renderers, camera, params, rgb=None, stats=False):
+        """rt_render_multi: one frame over several Renderers (one context each, the same scene uploaded to all):
+        tiles t % N == i rendered by renderer i, gathered on renderers[0]'s GPU.  Returns (rgb, [rt_stats] | None)."""
+        r0 = renderers[0]
+        cam = camera.to_c() if hasattr(camera, "to_c") else camera
+        H, W = params.height, params.width
+        if rgb is None:
+            rgb = np.zeros((H, W, 3), np.float32)
+        arr = (C.c_void_p * len(renderers))(*[r.scene for r in renderers])
+        st = (capi.rt_stats * len(renderers))() if stats else None
+        rc = r0.lib.rt_render_multi(arr, len(renderers), C.byref(cam), C.byref(params), rgb.ctypes.data, st)
+        r0._check(rc, "rt_render_multi")
+        return rgb, (list(st) if stats else None)
+
     def owned_tiles(self, params, rank, world):
         n = C.c_uint32()
         self._check(self.lib.rt_owned_tiles(C.byref(params), rank, world, C.byref(n)), "rt_owned_tiles")

@@ -74,6 +74,37 @@ def test_tile_split_is_bit_identical(gpu):
         assert util.bits_equal(acc, full)
 
 
+@pytest.mark.parametrize("n", [2, 3])
+def test_render_multi_contexts_reproduce_the_single_context_frame(gpu, n):
+    """rt_render_multi (the multi-GPU path of the C++ drop-in, one process, N contexts): N contexts — here all on
+    device 0, the only way a one-GPU box can run it — render tiles t % N == i each, slabs are gathered and
+    scattered on context 0.  The frame must equal the one-context frame (itself checked against the oracle and the
+    reference fixtures above) bit for bit; also with a render rectangle."""
+    from raytracer_amd.render import Renderer
+    name, world, params = CASES[2]
+    p = capi.rt_params.from_buffer_copy(params)
+    p.width, p.height, p.x1, p.y1 = 200, 136, 200, 136
+    flat = world.flatten()
+    gpu.upload(flat)
+    want, _, _, wst = gpu.render(world.camera, p)
+    others = [Renderer(0) for _ in range(n - 1)]
+    try:
+        for r in others:
+            r.upload(flat)
+        got, st = Renderer.render_multi([gpu] + others, world.camera, p, stats=True)
+        assert util.bits_equal(got, want)
+        assert sum(s.rays for s in st) == wst.rays and all(s.rays > 0 for s in st)
+        q = capi.rt_params.from_buffer_copy(p)
+        q.x0, q.x1, q.y0, q.y1 = 30, 170, 20, 120
+        part = np.full_like(want, -1.0)
+        Renderer.render_multi([gpu] + others, world.camera, q, rgb=part)
+        assert util.bits_equal(part[20:120, 30:170], want[20:120, 30:170])
+        assert (part[:20] == -1.0).all() and (part[:, :30] == -1.0).all()
+    finally:
+        for r in others:
+            r.close()
+
+
 def test_render_rectangle(gpu):
     """raytrace(beginY,endY,beginX,endX): a sub-rectangle equals the same pixels of the full frame."""
     name, world, params = CASES[0]

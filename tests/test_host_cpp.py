@@ -72,6 +72,12 @@ def test_cpp_scene_script_matches_the_reference_render(tmp_path):
     assert (d == 0).mean() >= 0.95
     ref_file, my_file = g["bmp"].tobytes(), open(out, "rb").read()
     assert len(my_file) == len(ref_file) and my_file[:54] == ref_file[:54]
+    # the same script on "three GPUs": three contexts (all on device 0 here) through rt_render_multi
+    out3 = str(tmp_path / "multi.bmp")
+    env = dict(os.environ, RT_GPU_DEVICES="0,0,0")
+    r = subprocess.run([EXE, str(tmp_path), out3, "160", "120"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr
+    assert open(out3, "rb").read() == my_file, "the multi-context render differs from the single-context one"
     out2 = str(tmp_path / "whole.bmp")
     r = subprocess.run([EXE, str(tmp_path), out2, "160", "120", "whole"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
