@@ -39,9 +39,11 @@ using namespace rt;
 #define RT_REP_DEN 4
 #endif
 
-template <bool AO, bool STATS>
+// MODE: BVH_CLOSEST (hit records), BVH_AO (distances only), BVH_SHADOW (any hit before the light ends the ray).
+template <int MODE, bool STATS>
 __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int counter, int next_counter)
 {
+    constexpr bool AO = MODE != BVH_CLOSEST;   // the queue layout of the distance-only queries: no bq_c, bq_cap slots
     // Per-lane stack of {reference, entry distance of its box}, [entry][lane] (conflict-free).  The distance lets
     // a pop discard an entry whose box has fallen behind the closest hit found since it was pushed without
     // fetching the node (18 % of the node fetches of an AO ray otherwise).
@@ -83,7 +85,8 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
     for (;;) {
         // ---- retire finished rays -------------------------------------------------------------
         if (active && cur == REF_NONE && npend == 0 && tri_left == 0) {
-            if (AO) key_min(&B.ao_key[dst], t_key(best.t));   // the ray's other items and k_ao's own hit meet here
+            if (MODE == BVH_AO) key_min(&B.ao_key[dst], t_key(best.t));   // the ray's other items and k_ao's own hit meet here
+            else if (MODE == BVH_SHADOW) { if (best.prim != H_MISS) B.sh_res[dst] = 0.0f; }   // k_shadow_defer stored what holds otherwise
             else { const q4 r = {best.t, u2f(best.prim), best.u, best.v}; B.hit[dst] = r; }
             active = false;
         }
@@ -106,7 +109,7 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
             }
             const uint32_t base = chunk_next, lim = chunk_end;
             chunk_next = base + nidle < lim ? base + nidle : lim;
-            if (STATS && AO) { dg[6]++; dg[7] += chunk_next - base; }
+            if (STATS && MODE == BVH_AO) { dg[6]++; dg[7] += chunk_next - base; }
             if (!active) {
                 const uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                 if (idx < lim) {   // items at or beyond the chunk end are left for the next refill
@@ -138,11 +141,11 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
         }
         // The winner of the vote is repeated (up to RT_*_REPS steps) while RT_REP_NUM/RT_REP_DEN of its voters
         // are ready again: the retire / refill / vote code above is a third of an iteration.
-        if (STATS && AO) { dg[4]++; dg[5] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(active)); }
+        if (STATS && MODE == BVH_AO) { dg[4]++; dg[5] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(active)); }
         if (n_node > n_tri) {
             bool cn = can_node;
             for (int rep = 0;; ++rep) {
-                if (STATS && AO) { dg[0]++; dg[1] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(cn)); }
+                if (STATS && MODE == BVH_AO) { dg[0]++; dg[1] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(cn)); }
                 if (cn) {
                     if (cur & REF_LEAF) {
                         pend[(npend++) * RT_BVH_BLOCK] = cur;   // a leaf that arrived as a root or waited for room (can_node: there is room now)
@@ -181,7 +184,7 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
         } else {
             bool ct = can_tri;
             for (int rep = 0;; ++rep) {
-                if (STATS && AO) { dg[2]++; dg[3] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ct)); }
+                if (STATS && MODE == BVH_AO) { dg[2]++; dg[3] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ct)); }
                 if (ct) {
                     if (tri_left == 0) {
                         const uint32_t ref = pend[(--npend) * RT_BVH_BLOCK];
@@ -202,7 +205,9 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
                     const float t = dot(v0v2, qvec) * invDet;
                     const bool ok = !(det < 0.000001f) && !(u < 0 || u > 1) && !(v < 0 || u + v > 1);
                     const uint32_t rank = f2u(e.w);
-                    if (AO) {   // only the distance leaves this kernel: the reference's first-wins rule on equal t cannot change it
+                    if (MODE == BVH_SHADOW) {   // all-opaque meshes: the first triangle before the light decides, the ray is done
+                        if (ok && t < best.t) { best.prim = H_TRI; sp = 0; npend = 0; tri_left = 1; cur = REF_NONE; }
+                    } else if (MODE == BVH_AO) {   // only the distance leaves this kernel: the reference's first-wins rule on equal t cannot change it
                         if (ok && t < best.t) best.t = t;
                     } else if (ok && closer(t, rank, best)) { best.t = t; best.prim = H_TRI | tri_next; best.u = u; best.v = v; best.rank = rank; }
                     tri_next++; tri_left--;
@@ -213,25 +218,29 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
             }
         }
     }
-    flush_counters<STATS>(cnt, B.stats, AO ? 2 : 0);
+    constexpr int cls = MODE == BVH_AO ? 2 : MODE == BVH_SHADOW ? 1 : 0;
+    flush_counters<STATS>(cnt, B.stats, cls);
     if (STATS) {
         for (int off = 32; off > 0; off >>= 1) nrays += __shfl_xor(nrays, off);
-        if (lane == 0) atomicAdd(&B.stats[ST_BVHRAYS + (AO ? 2 : 0)], (unsigned long long)nrays);
-        if (AO && lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&B.stats[ST_DIAG + k], (unsigned long long)dg[k]);
+        if (lane == 0) atomicAdd(&B.stats[ST_BVHRAYS + cls], (unsigned long long)nrays);
+        if (MODE == BVH_AO && lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&B.stats[ST_DIAG + k], (unsigned long long)dg[k]);
     }
 }
 
 
 namespace rt {
-void launch_k_bvh(bool ao, bool stats, hipStream_t stream, const DScene& S, const Batch& B, int counter, int next_counter)
+void launch_k_bvh(int mode, bool stats, hipStream_t stream, const DScene& S, const Batch& B, int counter, int next_counter)
 {
     const dim3 grid(RT_BVH_GRID), block(RT_BVH_BLOCK);
-    if (ao) {
-        if (stats) hipLaunchKernelGGL((k_bvh<true, true>), grid, block, 0, stream, S, B, counter, next_counter);
-        else hipLaunchKernelGGL((k_bvh<true, false>), grid, block, 0, stream, S, B, counter, next_counter);
+    if (mode == BVH_AO) {
+        if (stats) hipLaunchKernelGGL((k_bvh<BVH_AO, true>), grid, block, 0, stream, S, B, counter, next_counter);
+        else hipLaunchKernelGGL((k_bvh<BVH_AO, false>), grid, block, 0, stream, S, B, counter, next_counter);
+    } else if (mode == BVH_SHADOW) {
+        if (stats) hipLaunchKernelGGL((k_bvh<BVH_SHADOW, true>), grid, block, 0, stream, S, B, counter, next_counter);
+        else hipLaunchKernelGGL((k_bvh<BVH_SHADOW, false>), grid, block, 0, stream, S, B, counter, next_counter);
     } else {
-        if (stats) hipLaunchKernelGGL((k_bvh<false, true>), grid, block, 0, stream, S, B, counter, next_counter);
-        else hipLaunchKernelGGL((k_bvh<false, false>), grid, block, 0, stream, S, B, counter, next_counter);
+        if (stats) hipLaunchKernelGGL((k_bvh<BVH_CLOSEST, true>), grid, block, 0, stream, S, B, counter, next_counter);
+        else hipLaunchKernelGGL((k_bvh<BVH_CLOSEST, false>), grid, block, 0, stream, S, B, counter, next_counter);
     }
 }
 } // namespace rt

@@ -87,6 +87,7 @@ struct DScene {
     const DLight* lights; uint32_t num_lights;
     const DTexture* textures; const uint8_t* texels; uint32_t num_textures;
     const uint8_t* item_opaque; uint32_t num_items;  // 1: no transparent material below this scene entry
+    uint32_t shadow_defer;   // 1: every Mesh lies in an all-opaque entry: shadow rays queue their meshes for k_bvh<any hit>
     rt_ambient ambient;
     uint32_t prim_base_sphere, prim_base_tri;
     float cull_pad;      // conservative padding of the BVH culling test, relative (see bvh_traverse)
@@ -678,9 +679,11 @@ RT_FN uint32_t walk_gates(const DScene& S, f3 o, f3 d, const RayGate& rg, uint32
 //         1457-1460, 1548-1551) with rec.t starting at tmax.
 // MODE 1: Material::shadowed (main.cpp:40-76): closest hit per world->scene entry with
 //         rec.t = tmax; returns 1, 0 or 0.8 in `shadow`.
-// DEFER (closest-hit only): Mesh gates that pass are not traversed here; their BVH roots are left
-//         on the stack (up to RT_DEFER_ROOTS, more are drained inline) and the count is returned,
-//         so the caller can queue the ray for the compacted BVH kernel (bvh_item below).
+// DEFER (MODE 1 on scenes with DScene::shadow_defer, i.e. every Mesh sits in an all-opaque world->scene entry, where
+//         ANY triangle hit closer than tmax decides the query): Mesh gates that pass are not traversed here; their BVH
+//         roots are left on the stack and the count is returned (RT_DEFER_ROOTS + 1: more than one queue item
+//         carries, the walk was abandoned), so the caller can queue the ray for the any-hit variant of k_bvh.
+//         `shadow` is then the result as far as the primitives tested in place decide it.
 template <int MODE, bool STATS, bool DEFER = false>
 RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& shadow, Stack st, Counters& cnt)
 {
@@ -746,8 +749,14 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
         default: { // G_MESH: gate, then defer its triangle BVH to the shared drain loop
             if (STATS) cnt.gates++;
             if ((g.kind & G_SAME_BOX) || (gate_maybe(g.mn, g.mx, rg) && (gate_surely(g.mn, g.mx, o, d, rg) || box_intersects(g.mn, g.mx, o, d)))) {
+                if (DEFER) {   // the caller queues the roots for k_bvh; one more than an item carries: the caller's overflow path
+                    if (sp < RT_DEFER_ROOTS) st.p[sp * st.stride] = g.a;
+                    if (++sp > RT_DEFER_ROOTS) { i = n; break; }
+                    i++;
+                    break;
+                }
                 st.p[(sp++) * st.stride] = g.a;
-                if (sp >= (DEFER ? RT_DEFER_ROOTS : RT_PENDING_MAX)) {
+                if (sp >= RT_PENDING_MAX) {
                     const RayCull4 rc = make_cull4(S, o, d);
                     if (MODE == 1 && S.item_opaque[g.item]) {
                         if (bvh_drain<STATS, true>(S, o, d, rc, best, st, sp, cnt)) { shadowed = true; transparentOnly = false; i = n; break; }

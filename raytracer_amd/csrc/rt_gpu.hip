@@ -139,6 +139,47 @@ __global__ void __launch_bounds__(RT_SHADOW_BLOCK) k_shadow(DScene S, RenderArgs
     flush_counters<STATS>(cnt, B.stats, 1);
 }
 
+// Shadow rays of scenes with DScene::shadow_defer (shadow_defer_item): gate walk + queue append, no traversal.
+template <bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK) k_shadow_defer(DScene S, RenderArgs A, Batch B, int depth)
+{
+    __shared__ uint32_t s_stack[RT_DEFER_ROOTS * RT_BLOCK];
+    __shared__ GateNode s_gates[RT_LDS_GATES];
+    stage_gates(S, s_gates);
+    const uint32_t n = B.counters[C_SH + depth] < B.sh_cap ? B.counters[C_SH + depth] : B.sh_cap;
+    Stack st{s_stack + threadIdx.x, RT_BLOCK};
+    Counters cnt{0, 0, 0, 0};
+    QCursor qc{0, 0, queue_chunk(n, gridDim.x * (RT_BLOCK / 64), RT_QCHUNK)};
+    // wave-uniform trip count: every lane of a wave takes part in the queue cursor's ballots
+    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        bool overflow = false;
+        shadow_defer_item<STATS>(S, A, B, depth, i, i < n, st, cnt, qc, overflow);
+        if (__builtin_amdgcn_ballot_w64(overflow) != 0ull && (threadIdx.x & 63u) == 0u) {   // the wave's rays are redone by k_shadow_overflow
+            const uint32_t e = atomicAdd(&B.counters[C_SH_OVF + depth], 1u);
+            if (e < B.ovf_cap) B.ao_ovf[e] = base + (threadIdx.x & ~63u);
+        }
+    }
+    close_cursor(qc, B.bq_roots, (uint32_t)REF_NONE, B.bq_cap);
+    flush_counters<STATS>(cnt, B.stats, 1);
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(RT_OVF_BLOCK) k_shadow_overflow(DScene S, RenderArgs A, Batch B, int depth)
+{
+    const uint32_t count = B.counters[C_SH_OVF + depth] < B.ovf_cap ? B.counters[C_SH_OVF + depth] : B.ovf_cap;
+    if (blockIdx.x >= count) return;
+    __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_OVF_BLOCK];
+    __shared__ GateNode s_gates[RT_LDS_GATES];
+    stage_gates(S, s_gates);
+    const uint32_t n = B.counters[C_SH + depth] < B.sh_cap ? B.counters[C_SH + depth] : B.sh_cap;
+    Stack st{s_stack + threadIdx.x, RT_OVF_BLOCK};
+    Counters cnt{0, 0, 0, 0};
+    for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) shadow_overflow_item<STATS>(S, A, B, depth, B.ao_ovf[e], threadIdx.x, n, st, cnt);
+    cnt.rays = 0;   // counted by k_shadow_defer
+    flush_counters<STATS>(cnt, B.stats, 1);
+}
+
 // The hot AO kernel traverses nothing (ao_item): a stack of RT_DEFER_ROOTS mesh roots per lane is all it needs.
 template <bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
@@ -389,14 +430,14 @@ struct GpuBackend {
     void bvh_trace(const RenderArgs& A, int d)
     {
         timed(RT_K_TRACE_BVH, [&] {
-            launch_k_bvh(false, stats, stream, S, B, C_BQ + d, C_BQ_NEXT + d);
+            launch_k_bvh(BVH_CLOSEST, stats, stream, S, B, C_BQ + d, C_BQ_NEXT + d);
         });
     }
     void bvh_ao(const RenderArgs& A, int d)
     {
         if (S.ambient.occlusion_samples <= 0) return;
         timed(RT_K_AO_BVH, [&] {
-            launch_k_bvh(true, stats, stream, S, B, C_BQA + d, C_BQA_NEXT + d);
+            launch_k_bvh(BVH_AO, stats, stream, S, B, C_BQA + d, C_BQA_NEXT + d);
         });
     }
     void prep(const RenderArgs& A, int d, uint32_t n) { timed(RT_K_PREP, [&] { hipLaunchKernelGGL(k_prep, dim3(grid_d(d, n, RT_GRID_PREP)), dim3(RT_BLOCK), 0, stream, S, A, B, d, n); }); }
@@ -404,6 +445,19 @@ struct GpuBackend {
     {
         if (S.num_lights == 0) return;
         const uint32_t g = grid_many((uint64_t)B.P * S.num_lights * (RT_BLOCK / RT_SHADOW_BLOCK), d == 0 ? RT_GRID_SHADOW : RT_MAX_GRID);   // the queue cannot hold more than this; deeper levels are usually short
+        if (S.shadow_defer) {   // gate walk -> any-hit k_bvh over the queued meshes -> the (normally empty) overflow list
+            const uint32_t gd = grid_many((uint64_t)B.P * S.num_lights, d == 0 ? RT_GRID_SHADOW : RT_MAX_GRID);
+            timed(RT_K_SHADOW, [&] {
+                if (stats) hipLaunchKernelGGL(k_shadow_defer<true>, dim3(gd), dim3(RT_BLOCK), 0, stream, S, A, B, d);
+                else hipLaunchKernelGGL(k_shadow_defer<false>, dim3(gd), dim3(RT_BLOCK), 0, stream, S, A, B, d);
+            });
+            timed(RT_K_SHADOW, [&] { launch_k_bvh(BVH_SHADOW, stats, stream, S, B, C_BQS + d, C_BQS_NEXT + d); });
+            timed(RT_K_SHADOW, [&] {
+                if (stats) hipLaunchKernelGGL(k_shadow_overflow<true>, dim3(RT_MAX_GRID), dim3(RT_OVF_BLOCK), 0, stream, S, A, B, d);
+                else hipLaunchKernelGGL(k_shadow_overflow<false>, dim3(RT_MAX_GRID), dim3(RT_OVF_BLOCK), 0, stream, S, A, B, d);
+            });
+            return;
+        }
         timed(RT_K_SHADOW, [&] {
             if (stats) hipLaunchKernelGGL(k_shadow<true>, dim3(g), dim3(RT_SHADOW_BLOCK), 0, stream, S, A, B, d);
             else hipLaunchKernelGGL(k_shadow<false>, dim3(g), dim3(RT_SHADOW_BLOCK), 0, stream, S, A, B, d);
@@ -450,7 +504,7 @@ size_t carve_batch(Batch& B, char* base, uint32_t P, int levels, uint32_t nl, ui
     B.sh_cap = (uint32_t)std::min<size_t>(2 * (size_t)P * nl + (size_t)RT_GRID_PREP * (RT_BLOCK / 64) * RT_SHCHUNK, 0xFFFF0000u);
     B.sh_queue = (uint32_t*)take(4ull * B.sh_cap);
     B.ao_key = (uint32_t*)take(4ull * P * (n2 ? n2 : 1));
-    B.ovf_cap = (uint32_t)((uint64_t)P * (n2 ? n2 : 1) / 64u + 8u);   // one entry per wave and 64 items at most
+    B.ovf_cap = (uint32_t)(std::max<uint64_t>((uint64_t)P * (n2 ? n2 : 1), B.sh_cap) / 64u + 8u);   // one entry per wave of k_trace / k_shadow_defer / k_ao
     B.ao_ovf = (uint32_t*)take(4ull * B.ovf_cap);
     B.sh_res = (float*)take(4ull * P * nl);
     B.lvl = (q4*)take(sizeof(q4) * (size_t)P * levels);
@@ -464,6 +518,11 @@ size_t carve_batch(Batch& B, char* base, uint32_t P, int levels, uint32_t nl, ui
     if (n2) {   // the same for k_ao
         const size_t rays = (size_t)P * n2;
         const uint32_t waves = (uint32_t)std::min<size_t>((size_t)RT_GRID_AO * (RT_BLOCK / 64), (rays + 63) / 64);
+        B.bq_cap = std::max(B.bq_cap, (uint32_t)std::min<size_t>(rays + (size_t)waves * queue_chunk(rays, waves, RT_QCHUNK) + rays / 8, 0xFFFF0000u));
+    }
+    {   // and for k_shadow_defer (at most one item per shadow ray)
+        const size_t rays = (size_t)P * nl;
+        const uint32_t waves = (uint32_t)std::min<size_t>((size_t)RT_GRID_SHADOW * (RT_BLOCK / 64), (rays + 63) / 64);
         B.bq_cap = std::max(B.bq_cap, (uint32_t)std::min<size_t>(rays + (size_t)waves * queue_chunk(rays, waves, RT_QCHUNK) + rays / 8, 0xFFFF0000u));
     }
     B.bq_a = (q4*)take(sizeof(q4) * (size_t)B.bq_cap);
@@ -706,6 +765,7 @@ int rt_scene_commit(rt_scene* s)
     D.num_lights = (uint32_t)H.dlights.size();
     D.num_textures = (uint32_t)H.dtextures.size();
     D.num_items = (uint32_t)H.item_opaque.size();
+    D.shadow_defer = H.shadow_defer ? 1u : 0u;
     D.ambient = H.ambient;
     D.prim_base_sphere = (uint32_t)H.planes.size();
     D.prim_base_tri = (uint32_t)(H.planes.size() + H.spheres.size());
@@ -875,6 +935,7 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
     B.stats = fixed_mem ? (unsigned long long*)(fixed_mem + align_up(sizeof(uint32_t) * C_TOTAL, 256)) : ctx->d_stats;
 
     GpuBackend be{ctx, S, B, stream, (p->flags & RT_FLAG_STATS) != 0, (p->flags & RT_FLAG_TIMING) != 0, levels_alloc};
+    if ((S.debug & 4u) || (uint64_t)P * nl >= (1ull << 29)) be.S.shadow_defer = 0;   // experiment switch / the queue item's 29-bit destination
     {   // the batch buffers, counters and statistics are the context's: wait for their previous user (any stream)
         const int rc = order_after_previous_work(ctx, stream);
         if (rc) return rc;

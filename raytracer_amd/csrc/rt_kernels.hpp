@@ -47,6 +47,6 @@ __device__ inline void flush_counters(const Counters& c, unsigned long long* sta
 
 
 // rt_bvh.hip: k_bvh<ao, stats> on RT_BVH_GRID x RT_BVH_BLOCK over the queue counted by counters[counter]
-void launch_k_bvh(bool ao, bool stats, hipStream_t stream, const DScene& S, const Batch& B, int counter, int next_counter);
+void launch_k_bvh(int mode /* BVH_CLOSEST, BVH_AO, BVH_SHADOW */, bool stats, hipStream_t stream, const DScene& S, const Batch& B, int counter, int next_counter);
 
 } // namespace rt

@@ -23,7 +23,8 @@ namespace rt {
 
 enum : uint8_t { LK_NONE = 0, LK_TERMINAL = 1, LK_MIRROR = 2, LK_REFRACT = 3 };
 // (C_AO counts the entries of Batch::ao_ovf)
-enum { C_QUEUE = 0, C_AO = 64, C_SH = 128, C_BQ = 192, C_BQA = 256, C_BQ_NEXT = 320, C_BQA_NEXT = 384, C_TR_OVF = 448 /* entries of Batch::ao_ovf written by k_trace */, C_TOTAL = 512 };   // per-batch u32 counters, one per depth
+enum { C_QUEUE = 0, C_AO = 64, C_SH = 128, C_BQ = 192, C_BQA = 256, C_BQ_NEXT = 320, C_BQA_NEXT = 384, C_TR_OVF = 448 /* entries of Batch::ao_ovf written by k_trace */,
+       C_BQS = 512, C_BQS_NEXT = 576 /* the work queue as the shadow pass uses it */, C_SH_OVF = 640 /* entries of Batch::ao_ovf written by k_shadow_defer */, C_TOTAL = 704 };   // per-batch u32 counters, one per depth
 enum { ST_SHADOW = 0, ST_AO = 1, ST_BOUNCE = 2, ST_NODES = 3, ST_TRIS = 6, ST_GATES = 9, ST_BVHRAYS = 12,
        ST_DIAG = 15 /* k_bvh<AO> lane-packing diagnostics of the counting variant: node steps, lanes in them, triangle steps, lanes in them, votes, active lanes at votes, refills, lanes refilled */,
        ST_TOTAL = 23 }; // u64
@@ -284,24 +285,28 @@ RT_FN void trace_overflow_item(const DScene& S, const RenderArgs& A, const Batch
 }
 
 // One item of the compacted BVH kernel: every lane holds a ray that has triangle BVHs to search.
-// AO = 0: closest-hit query, result -> hit[dst];  AO = 1: occlusion distance -> ao_t[dst].
-template <bool AO, bool STATS>
+// MODE 0: closest-hit query, result -> hit[dst];  MODE 1: occlusion distance -> minimum into ao_key[dst];
+// MODE 2: shadow query over all-opaque meshes: any triangle closer than the light -> sh_res[dst] = 0.
+enum { BVH_CLOSEST = 0, BVH_AO = 1, BVH_SHADOW = 2 };
+template <int MODE, bool STATS>
 RT_FN void bvh_item(const DScene& S, const Batch& B, uint32_t idx, Stack st, Counters& cnt)
 {
     q4 a = B.bq_a[idx], b = B.bq_b[idx];
     f3 o = xyz(a), d = xyz(b);
     Hit best; best.t = a.w; best.prim = H_MISS; best.rank = 0; best.u = 0; best.v = 0;
-    if (!AO) { q4 c = B.bq_c[idx]; best.prim = f2u(c.x); best.rank = f2u(c.y); best.u = c.z; best.v = c.w; }
+    if (MODE == BVH_CLOSEST) { q4 c = B.bq_c[idx]; best.prim = f2u(c.x); best.rank = f2u(c.y); best.u = c.z; best.v = c.w; }
     RayCull4 rc = make_cull4(S, o, d);
     const uint32_t nroots = (f2u(b.w) >> 29) + 1u, dst = f2u(b.w) & 0x1FFFFFFFu;
     if (B.bq_roots[idx] == REF_NONE) return;   // hole
     for (uint32_t k = 0; k < nroots; ++k) {
         uint32_t sp = 1;
         st.p[0] = B.bq_roots[(size_t)k * B.bq_cap + idx];
-        bvh_drain<STATS, false>(S, o, d, rc, best, st, sp, cnt);
+        if (MODE == BVH_SHADOW) {
+            if (bvh_drain<STATS, true>(S, o, d, rc, best, st, sp, cnt)) { B.sh_res[dst] = 0.0f; return; }
+        } else bvh_drain<STATS, false>(S, o, d, rc, best, st, sp, cnt);
     }
-    if (AO) key_min(&B.ao_key[dst], t_key(best.t));
-    else { q4 r = {best.t, u2f(best.prim), best.u, best.v}; B.hit[dst] = r; }
+    if (MODE == BVH_AO) key_min(&B.ao_key[dst], t_key(best.t));
+    else if (MODE == BVH_CLOSEST) { q4 r = {best.t, u2f(best.prim), best.u, best.v}; B.hit[dst] = r; }
 }
 
 // Returns true when the path's material consumes shadow rays (Specular / Textured); P and N are then
@@ -417,6 +422,53 @@ RT_FN void shadow_item(const DScene& S, const RenderArgs& A, const Batch& B, int
     Hit h; float sh = 1.0f;
     trace<1, STATS>(S, src, dir, dist, h, sh, st, cnt);
     B.sh_res[e] = sh;
+}
+
+// The same query on a scene whose Meshes all lie in all-opaque world->scene entries (DScene::shadow_defer): the hot
+// kernel traverses nothing.  What the primitives tested in place decide is stored at once (1, 0.8 or 0); unless that
+// is already 0, the roots of the Meshes whose gates pass ride in one queue item for k_bvh<BVH_SHADOW>, which stores 0
+// when any of their triangles lies before the light.  More than RT_DEFER_ROOTS such Meshes, or a full queue, set
+// `overflow`: the wave's rays are redone in place by shadow_overflow_item after k_bvh has run.
+// GPU: called by all 64 lanes of a wave (`valid` = false for lanes without an item): the queue cursor votes.
+template <bool STATS>
+RT_FN void shadow_defer_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, bool valid, Stack st, Counters& cnt,
+                             QCursor& qc, bool& overflow)
+{
+    uint32_t e = valid ? B.sh_queue[idx] : 0xFFFFFFFFu, sp = 0;
+    valid = e != 0xFFFFFFFFu;   // hole left by the chunked appends
+    f3 src = F3(0, 0, 0), dir = F3(0, 0, 1);
+    float dist = 0.0f;
+    if (valid) {
+        cnt.rays++;
+        const uint32_t p = e / S.num_lights, l = e % S.num_lights;
+        const q4 o4 = B.ray_o[depth & 1][p], d4 = B.ray_d[depth & 1][p];
+        const f3 P = xyz(o4) + xyz(d4) * B.hit[p].x;
+        src = light_source(S.lights[l], P);
+        dir = normalize(P - src);
+        dist = length(P - src) - 0.01f;
+        Hit h; float sh = 1.0f;
+        sp = trace<1, STATS, true>(S, src, dir, dist, h, sh, st, cnt);
+        if (sp > RT_DEFER_ROOTS) { overflow = true; sp = 0; }
+        if (sh == 0.0f) sp = 0;   // decided
+        B.sh_res[e] = sh;
+    }
+    const bool want = sp > 0;
+    const uint32_t slot = chunk_append<RT_QCHUNK>(&B.counters[C_BQS + depth], want, qc, B.bq_roots, (uint32_t)REF_NONE, B.bq_cap);
+    if (want) {
+        if (slot < B.bq_cap) {
+            const q4 a = {src.x, src.y, src.z, dist};
+            const q4 b = {dir.x, dir.y, dir.z, u2f(e | ((sp - 1u) << 29))};   // e < 2^29 (checked where shadow_defer is decided)
+            B.bq_a[slot] = a; B.bq_b[slot] = b;
+            for (uint32_t k = 0; k < sp; ++k) B.bq_roots[(size_t)k * B.bq_cap + slot] = st.p[k * st.stride];
+        } else overflow = true;   // queue full
+    }
+}
+
+// The rays of a wave of shadow_defer_item that set `overflow`, each traversed in place.  `entry` = the wave's first item.
+template <bool STATS>
+RT_FN void shadow_overflow_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t entry, uint32_t lane, uint32_t n, Stack st, Counters& cnt)
+{
+    if (entry + lane < n) shadow_item<STATS>(S, A, B, depth, entry + lane, st, cnt);
 }
 
 // AO work item -> (slot, stratum k).  Blocked stratum-major order: RT_AO_BLOCK consecutive slots x all n*n
@@ -654,7 +706,7 @@ void render_frame(Backend& be, RenderArgs A, uint32_t owned_tiles, uint32_t tile
             be.bvh_trace(A, d);
             be.trace_overflow(A, d, paths);
             be.prep(A, d, paths);
-            be.shadow(A, d);
+            be.shadow(A, d);          // on scenes with shadow_defer: shadow_defer -> bvh<shadow> -> shadow_overflow
             be.ao(A, d, paths);
             be.bvh_ao(A, d);
             be.ao_overflow(A, d, paths);

@@ -754,6 +754,15 @@ int HostScene::build()
         item_opaque.push_back(subtree_opaque(scene[i]) ? 1 : 0);
     }
     if (item_opaque.empty()) item_opaque.push_back(1);
+    // Shadow rays may hand their meshes to the any-hit BVH kernel when no Mesh shares a world->scene entry with a
+    // transparent material (Material::shadowed needs the entry's CLOSEST hit then, main.cpp:52-70).
+    shadow_defer = false;
+    {
+        bool any_mesh = false, all_opaque = true;
+        for (const GateNode& g : gates)
+            if ((g.kind & G_KIND_MASK) == G_MESH) { any_mesh = true; all_opaque = all_opaque && item_opaque[g.item] != 0; }
+        shadow_defer = any_mesh && all_opaque;
+    }
     // A gate whose box is bit-identical to the enclosing gate's (a MultiMesh of one Mesh) repeats a test
     // that has just passed: flag it.  `extent` (the scale of the conservative paddings) covers gate boxes too.
     {

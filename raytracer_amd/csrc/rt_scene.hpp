@@ -40,6 +40,7 @@ struct HostScene {
     std::vector<DTexture> dtextures;
     std::vector<uint8_t> texels;
     std::vector<uint8_t> item_opaque;
+    bool shadow_defer = false;   // see DScene::shadow_defer
     float extent = 0.0f;
     bool has_bounce_materials = false;
     uint32_t bvh_max_depth = 0;

@@ -38,16 +38,30 @@ struct LoopBackend {
     }
     void bvh_trace(const RenderArgs& A, int d) {
         Stack st{stack.data(), 1};
-        for (uint32_t i = 0, n = std::min(B.counters[C_BQ + d], B.cq_cap); i < n; ++i) bvh_item<false, true>(S, B, i, st, cnt[0]);
+        for (uint32_t i = 0, n = std::min(B.counters[C_BQ + d], B.cq_cap); i < n; ++i) bvh_item<BVH_CLOSEST, true>(S, B, i, st, cnt[0]);
     }
     void bvh_ao(const RenderArgs& A, int d) {
         Stack st{stack.data(), 1};
-        for (uint32_t i = 0, n = std::min(B.counters[C_BQA + d], B.bq_cap); i < n; ++i) bvh_item<true, true>(S, B, i, st, cnt[2]);
+        for (uint32_t i = 0, n = std::min(B.counters[C_BQA + d], B.bq_cap); i < n; ++i) bvh_item<BVH_AO, true>(S, B, i, st, cnt[2]);
     }
     void prep(const RenderArgs& A, int d, uint32_t fixed) { QCursor q{0, 0}; for (uint32_t i = 0, n = count(d, fixed); i < n; ++i) prep_item(S, A, B, d, i, true, q); }
     void shadow(const RenderArgs& A, int d) {
         Stack st{stack.data(), 1};
-        for (uint32_t i = 0, n = B.counters[C_SH + d]; i < n; ++i) shadow_item<true>(S, A, B, d, i, st, cnt[1]);
+        const uint32_t n = B.counters[C_SH + d];
+        if (!S.shadow_defer) {
+            for (uint32_t i = 0; i < n; ++i) shadow_item<true>(S, A, B, d, i, st, cnt[1]);
+            return;
+        }
+        QCursor qc{0, 0};
+        for (uint32_t i = 0; i < n; ++i) {
+            bool overflow = false;
+            shadow_defer_item<true>(S, A, B, d, i, true, st, cnt[1], qc, overflow);
+            if (overflow) B.ao_ovf[B.counters[C_SH_OVF + d]++] = i;   // a "wave" of one lane
+        }
+        for (uint32_t i = 0, m = std::min(B.counters[C_BQS + d], B.bq_cap); i < m; ++i) bvh_item<BVH_SHADOW, true>(S, B, i, st, cnt[1]);
+        const uint32_t rays = cnt[1].rays;
+        for (uint32_t e = 0; e < B.counters[C_SH_OVF + d]; ++e) shadow_overflow_item<true>(S, A, B, d, B.ao_ovf[e], 0, n, st, cnt[1]);
+        cnt[1].rays = rays;   // counted by shadow_defer_item
     }
     void ao(const RenderArgs& A, int d, uint32_t fixed) {
         Stack st{stack.data(), 1};
@@ -107,7 +121,7 @@ int emul_render(const rt_scene_desc* d, const rt_camera* cam, const rt_params* p
     S.tri_attr = H.attr4.data(); S.nodes = H.nodes4.data();
     S.materials = H.dmaterials.data(); S.lights = H.dlights.data(); S.num_lights = (uint32_t)H.dlights.size();
     S.textures = H.dtextures.data(); S.texels = H.texels.data(); S.num_textures = (uint32_t)H.dtextures.size();
-    S.item_opaque = H.item_opaque.data(); S.num_items = (uint32_t)H.item_opaque.size();
+    S.item_opaque = H.item_opaque.data(); S.num_items = (uint32_t)H.item_opaque.size(); S.shadow_defer = H.shadow_defer ? 1u : 0u;
     S.ambient = H.ambient;
     S.prim_base_sphere = (uint32_t)H.planes.size(); S.prim_base_tri = (uint32_t)(H.planes.size() + H.spheres.size());
     S.cull_pad = 1.0f / 262144.0f; S.extent = H.extent; S.debug = 0;
