@@ -622,11 +622,11 @@ RT_FN uint32_t lead_planes_hit(const DScene& S, f3 o, f3 d, Hit& best)
 // pushed on `st`.  Walks from node i until the array ends or RT_DEFER_ROOTS roots wait; returns the index to
 // resume at (>= S.num_gates: done).  Nothing is traversed here: the caller queues the roots for k_bvh and calls
 // again, so this walk needs 8 stack entries and no traversal code (the kernel that runs it stays small).
+// One node of that walk: tests gate node i and returns the index of the node to visit next.
 template <bool STATS>
-RT_FN uint32_t walk_gates(const DScene& S, f3 o, f3 d, const RayGate& rg, uint32_t i, Hit& best, Stack st, uint32_t& sp, Counters& cnt)
+RT_FN uint32_t gate_step(const DScene& S, f3 o, f3 d, const RayGate& rg, uint32_t i, Hit& best, Stack st, uint32_t& sp, Counters& cnt)
 {
-    const uint32_t n = S.num_gates;
-    while (i < n && sp < RT_DEFER_ROOTS) {
+    {
         const GateNode g = load_gate(S, i);
         switch (g.kind & G_KIND_MASK) {
         case G_GROUP:
@@ -671,6 +671,14 @@ RT_FN uint32_t walk_gates(const DScene& S, f3 o, f3 d, const RayGate& rg, uint32
             break;
         }
     }
+    return i;
+}
+
+template <bool STATS>
+RT_FN uint32_t walk_gates(const DScene& S, f3 o, f3 d, const RayGate& rg, uint32_t i, Hit& best, Stack st, uint32_t& sp, Counters& cnt)
+{
+    const uint32_t n = S.num_gates;
+    while (i < n && sp < RT_DEFER_ROOTS) i = gate_step<STATS>(S, o, d, rg, i, best, st, sp, cnt);
     return i;
 }
 

@@ -207,6 +207,122 @@ __global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B
     flush_counters<STATS>(cnt, B.stats, 2);
 }
 
+// The AO gate walk for scenes with MANY gate nodes (the reference's BVHAccel over thousands of shapes: config 5).
+// There a ray tests ~100 nodes, the walks of a wave's 64 rays differ in length by 2-3x, and k_ao above idles every
+// lane until the wave's longest walk ends (43 % active lanes).  Here the waves are persistent, claim chunks of
+// RT_WALK_CHUNK consecutive AO items with one atomic, and their lanes REFILL from the chunk as their walks end, as
+// k_bvh does with its queue: every round each lane holding a ray takes up to RT_WALK_REPS gate nodes (gate_step),
+// finished rays store their distance, rays with RT_DEFER_ROOTS roots (or at the end of their walk) append a queue
+// item, idle lanes fetch the next items once RT_WALK_REFILL of them wait.  Same results as ao_item (only the
+// position of a ray's items in the queue changes).  Measured on config 5 (k_ao 56.0 ms): 50.4 ms — the lanes of a
+// wave no longer sit on the same gate node, so the node fetches stop coalescing (each lane-step is its own 48-byte
+// gather from L2), which eats most of what the fuller waves gain; refill at 8-32 idle lanes, 8-64 steps per round
+// and chunks of 128-1024 items are within 3 % of each other, 4096-item chunks or a static split lose the gain to the
+// end-of-launch imbalance.  On scenes with few gate nodes (config 3: 2 per ray) k_ao stays in use.
+#ifndef RT_WALK_REPS
+#define RT_WALK_REPS 32
+#endif
+#ifndef RT_WALK_REFILL
+#define RT_WALK_REFILL 16
+#endif
+#ifndef RT_GRID_AO_WALK
+#define RT_GRID_AO_WALK RT_MAX_GRID   // persistent: the waves claim chunks of items
+#endif
+#ifndef RT_WALK_CHUNK
+#define RT_WALK_CHUNK 512u            // items per claim, a multiple of 64
+#endif
+template <bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK) k_ao_walk(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
+{
+    __shared__ uint32_t s_stack[RT_DEFER_ROOTS * RT_BLOCK];
+    __shared__ GateNode s_gates[RT_LDS_GATES];
+    stage_gates(S, s_gates);
+    const uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
+    const uint32_t nslots = depth == 0 ? fixed_n : B.counters[C_QUEUE + depth];
+    const uint32_t n = nslots * n2;
+    const uint32_t waves = gridDim.x * (RT_BLOCK / 64);
+    const uint32_t lane = threadIdx.x & 63u;
+    if ((uint64_t)(blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6)) * 64u >= n) return;   // more waves than groups of 64 items
+    uint32_t next = 0, end = 0;   // wave-uniform: the claimed range of items still to hand out
+    bool exhausted = false;
+    Stack st{s_stack + threadIdx.x, RT_BLOCK};
+    Counters cnt{0, 0, 0, 0};
+    QCursor qc{0, 0, queue_chunk(n, waves, RT_QCHUNK)};
+    const uint32_t ng = S.num_gates;
+    bool active = false;
+    f3 o = F3(0, 0, 0), dir = F3(0, 0, 1);
+    RayGate rg = {};
+    Hit h; h.t = 0; h.prim = H_MISS; h.u = 0; h.v = 0; h.rank = 0;
+    uint32_t dst = 0, sp = 0, i = ng, item = 0;
+    for (;;) {
+        // ---- rays whose walk ended or whose root stack is full: queue item, distance ----
+        const bool done = active && i >= ng;
+        const bool want = active && sp > 0 && (done || sp >= RT_DEFER_ROOTS);
+        const uint32_t slot = chunk_append<RT_QCHUNK>(&B.counters[C_BQA + depth], want, qc, B.bq_roots, (uint32_t)REF_NONE, B.bq_cap);
+        if (want) {
+            if (slot < B.bq_cap) {
+                const q4 a = {o.x, o.y, o.z, h.t};
+                const q4 b = {dir.x, dir.y, dir.z, u2f(dst | ((sp - 1u) << 29))};
+                B.bq_a[slot] = a; B.bq_b[slot] = b;
+                for (uint32_t r = 0; r < sp; ++r) B.bq_roots[(size_t)r * B.bq_cap + slot] = st.p[r * st.stride];
+            } else {   // queue full: the ray's group of 64 items is redone by k_ao_overflow (entered once)
+                const uint32_t g = item >> 6;
+                if (!(atomicOr(&B.ovf_bits[g >> 5], 1u << (g & 31u)) & (1u << (g & 31u)))) {
+                    const uint32_t e = atomicAdd(&B.counters[C_AO + depth], 1u);
+                    if (e < B.ovf_cap) B.ao_ovf[e] = g << 6;
+                }
+            }
+            sp = 0;
+        }
+        if (done) { B.ao_key[dst] = t_key(h.t); active = false; }
+        // ---- refill ----
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(!active);
+        const uint32_t nidle = (uint32_t)__popcll(idle);
+        if (next >= end && !exhausted && nidle >= RT_WALK_REFILL) {   // claim the next RT_WALK_CHUNK items (whole groups of 64)
+            uint32_t b0 = 0;
+            if (lane == 0) b0 = atomicAdd(&B.counters[C_AOW + depth], (uint32_t)RT_WALK_CHUNK);
+            b0 = __shfl(b0, 0);
+            next = b0 < n ? b0 : n; end = b0 + RT_WALK_CHUNK < n ? b0 + RT_WALK_CHUNK : n;
+            exhausted = b0 >= n || n - b0 <= RT_WALK_CHUNK;   // n < 2^29: no wrap
+        }
+        if (next < end && nidle >= RT_WALK_REFILL) {
+            const uint32_t mine = next + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!active && mine < end) {
+                item = mine;
+                uint32_t slot_ao, k;
+                ao_coords(S, nslots, item & ~255u, item & 255u, slot_ao, k);
+                const q4 rw = B.ao_w[slot_ao];
+                if (f2u(rw.w) != 0xFFFFFFFFu) {   // else: a path without AO rays
+                    const q4 ro = B.ao_o[slot_ao], ru = B.ao_u[slot_ao];
+                    cnt.rays++;
+                    o = xyz(ro);
+                    dir = ao_dir(S.ambient, xyz(ru), xyz(rw), f2u(ro.w), f2u(rw.w), k);
+                    dst = slot_ao * n2 + k;
+                    rg = make_gate(S.cull_pad, S.extent, o, dir);
+                    h.t = S.ambient.occlusion_dist; h.prim = H_MISS; h.rank = 0;
+                    i = (S.debug & 2u) ? ng : lead_planes_hit(S, o, dir, h);
+                    sp = 0;
+                    active = true;
+                }
+            }
+            next = next + nidle < end ? next + nidle : end;
+        }
+        if (__builtin_amdgcn_ballot_w64(active) == 0ull) {
+            if (next >= end && exhausted) break;
+            continue;
+        }
+        // ---- RT_WALK_REPS gate nodes per lane ----
+#pragma nounroll
+        for (int rep = 0; rep < RT_WALK_REPS; ++rep) {
+            const bool go = active && i < ng && sp < RT_DEFER_ROOTS;
+            if (__builtin_amdgcn_ballot_w64(go) == 0ull) break;
+            if (go) i = gate_step<STATS>(S, o, dir, rg, i, h, st, sp, cnt);
+        }
+    }
+    close_cursor(qc, B.bq_roots, (uint32_t)REF_NONE, B.bq_cap);
+    flush_counters<STATS>(cnt, B.stats, 2);
+}
+
 template <bool STATS>
 __global__ void __launch_bounds__(RT_OVF_BLOCK) k_ao_overflow(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
 {
@@ -380,6 +496,7 @@ struct GpuBackend {
     std::vector<Span> spans;
     size_t ev_used = 0;
     hipError_t err = hipSuccess;
+    bool walk_refill = false; size_t ovf_bits_bytes = 0;   // k_ao_walk instead of k_ao (scenes with many gate nodes)
 
     size_t ev()
     {
@@ -402,6 +519,10 @@ struct GpuBackend {
     {
         hipError_t r = hipMemsetAsync(B.counters, 0, sizeof(uint32_t) * C_TOTAL, stream);
         if (r != hipSuccess) err = r;
+        if (walk_refill) {
+            r = hipMemsetAsync(B.ovf_bits, 0, ovf_bits_bytes, stream);
+            if (r != hipSuccess) err = r;
+        }
     }
     void raygen(const RenderArgs& A, uint32_t n) { timed(RT_K_RAYGEN, [&] { hipLaunchKernelGGL(k_raygen, dim3(grid_for(n)), dim3(RT_BLOCK), 0, stream, S, A, B, n); }); }
     // many short blocks for the uneven kernels, but at least 16 items per thread (small frames: the per-block set-up
@@ -466,6 +587,14 @@ struct GpuBackend {
     void ao(const RenderArgs& A, int d, uint32_t n)
     {
         if (S.ambient.occlusion_samples <= 0) return;
+        if (walk_refill) {   // many gate nodes: the refilling walk (k_ao_walk)
+            const uint32_t gw = grid_many((uint64_t)n * (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples), d == 0 ? RT_GRID_AO_WALK : RT_MAX_GRID);
+            timed(RT_K_AO, [&] {
+                if (stats) hipLaunchKernelGGL(k_ao_walk<true>, dim3(gw), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
+                else hipLaunchKernelGGL(k_ao_walk<false>, dim3(gw), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
+            });
+            return;
+        }
         const uint32_t g = grid_many((uint64_t)n * (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples), d == 0 ? RT_GRID_AO : RT_MAX_GRID);
         timed(RT_K_AO, [&] {
             if (stats) hipLaunchKernelGGL(k_ao<true>, dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
@@ -506,6 +635,7 @@ size_t carve_batch(Batch& B, char* base, uint32_t P, int levels, uint32_t nl, ui
     B.ao_key = (uint32_t*)take(4ull * P * (n2 ? n2 : 1));
     B.ovf_cap = (uint32_t)(std::max<uint64_t>((uint64_t)P * (n2 ? n2 : 1), B.sh_cap) / 64u + 8u);   // one entry per wave of k_trace / k_shadow_defer / k_ao
     B.ao_ovf = (uint32_t*)take(4ull * B.ovf_cap);
+    B.ovf_bits = (uint32_t*)take(4ull * (B.ovf_cap / 32u + 1u));
     B.sh_res = (float*)take(4ull * P * nl);
     B.lvl = (q4*)take(sizeof(q4) * (size_t)P * levels);
     B.lvl_ph = (float*)take(4ull * P * levels * (nl > 1 ? nl - 1 : 1));
@@ -935,6 +1065,9 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
     B.stats = fixed_mem ? (unsigned long long*)(fixed_mem + align_up(sizeof(uint32_t) * C_TOTAL, 256)) : ctx->d_stats;
 
     GpuBackend be{ctx, S, B, stream, (p->flags & RT_FLAG_STATS) != 0, (p->flags & RT_FLAG_TIMING) != 0, levels_alloc};
+    // the refilling gate walk pays off when a ray tests many gate nodes (config 5: ~100 of 7500; config 3: 2 of 8)
+    be.walk_refill = ((S.num_gates > RT_LDS_GATES && !(S.debug & 32u)) || (S.debug & 16u)) && n2 > 0;
+    be.ovf_bits_bytes = 4ull * (B.ovf_cap / 32u + 1u);
     if ((S.debug & 4u) || (uint64_t)P * nl >= (1ull << 29)) be.S.shadow_defer = 0;   // experiment switch / the queue item's 29-bit destination
     {   // the batch buffers, counters and statistics are the context's: wait for their previous user (any stream)
         const int rc = order_after_previous_work(ctx, stream);

@@ -24,7 +24,8 @@ namespace rt {
 enum : uint8_t { LK_NONE = 0, LK_TERMINAL = 1, LK_MIRROR = 2, LK_REFRACT = 3 };
 // (C_AO counts the entries of Batch::ao_ovf)
 enum { C_QUEUE = 0, C_AO = 64, C_SH = 128, C_BQ = 192, C_BQA = 256, C_BQ_NEXT = 320, C_BQA_NEXT = 384, C_TR_OVF = 448 /* entries of Batch::ao_ovf written by k_trace */,
-       C_BQS = 512, C_BQS_NEXT = 576 /* the work queue as the shadow pass uses it */, C_SH_OVF = 640 /* entries of Batch::ao_ovf written by k_shadow_defer */, C_TOTAL = 704 };   // per-batch u32 counters, one per depth
+       C_BQS = 512, C_BQS_NEXT = 576 /* the work queue as the shadow pass uses it */, C_SH_OVF = 640 /* entries of Batch::ao_ovf written by k_shadow_defer */,
+       C_AOW = 704 /* k_ao_walk: next unclaimed AO item */, C_TOTAL = 768 };   // per-batch u32 counters, one per depth
 enum { ST_SHADOW = 0, ST_AO = 1, ST_BOUNCE = 2, ST_NODES = 3, ST_TRIS = 6, ST_GATES = 9, ST_BVHRAYS = 12,
        ST_DIAG = 15 /* k_bvh<AO> lane-packing diagnostics of the counting variant: node steps, lanes in them, triangle steps, lanes in them, votes, active lanes at votes, refills, lanes refilled */,
        ST_TOTAL = 23 }; // u64
@@ -47,6 +48,7 @@ struct Batch {
                            // k_ao stores the closest of the primitives it tests in place, k_bvh / k_ao_overflow take minima
     uint32_t* ao_ovf;      // waves of k_ao (first item index) that found the BVH work queue full: redone by k_ao_overflow
     uint32_t ovf_cap;
+    uint32_t* ovf_bits;    // GPU, k_ao_walk: one bit per 64 AO items, set when the group was entered in ao_ovf (its lanes hold items of many groups)
     float* sh_res;         // [p * num_lights + light]
     q4* lvl;               // [d*P + p]  TERMINAL: final colour; MIRROR: {ambient term, phong of light 0}
     float* lvl_ph;         // [(d*P + p)*(num_lights-1) + (l-1)] phong of lights 1..

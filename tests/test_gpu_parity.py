@@ -208,16 +208,18 @@ def test_full_size_crop_against_oracle(port, config3_full):
 
 
 @pytest.mark.gpu
-def test_bvh_queue_overflow_falls_back_inline(gpu):
+@pytest.mark.parametrize("debug", ["8", "24"])
+def test_bvh_queue_overflow_falls_back_inline(gpu, debug):
     """RT_DEBUG=8 (read at rt_scene_commit) caps the compacted BVH queue at 3000 items, so most
-    mesh rays take the inline traversal in k_trace / k_ao and the chunked appends run past the
-    capacity: the frame must not change by a bit."""
+    mesh rays are redone by the overflow kernels (k_trace_overflow / k_shadow_overflow / k_ao_overflow) and the
+    chunked appends run past the capacity: the frame must not change by a bit.  24 = the same with the refilling
+    AO gate walk (k_ao_walk, RT_DEBUG bit 16), whose overflow list is entered per group of 64 items."""
     import os
     name, world, params = CASES[0]
     p = capi.rt_params.from_buffer_copy(params)
     gpu.upload(world)
     want, wid, wt, _ = gpu.render(world.camera, p, ids=True)
-    os.environ["RT_DEBUG"] = "8"
+    os.environ["RT_DEBUG"] = debug
     try:
         gpu.upload(world)
         got, gid, gt, _ = gpu.render(world.camera, p, ids=True)
@@ -225,6 +227,22 @@ def test_bvh_queue_overflow_falls_back_inline(gpu):
         del os.environ["RT_DEBUG"]
         gpu.upload(world)
     assert np.array_equal(gid, wid) and util.bits_equal(gt, wt) and util.bits_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_refilling_gate_walk_matches_the_oracle(gpu, port):
+    """k_ao_walk (the AO gate walk of scenes with more than 64 gate nodes, where lanes refill as their walks end)
+    forced on small scenes by RT_DEBUG=16: against the oracle like every other case, incl. the scene whose rays cross
+    14 meshes (several queue items per ray).  test_other_configs[config5] runs it unforced (1200 gate nodes)."""
+    import os
+    os.environ["RT_DEBUG"] = "16"
+    try:
+        for name, world, params in [c for c in CASES if c[0] in ("default_d2_ao", "default_jitter4_ao_nonsquare", "config3_textured_mesh", "config5_instanced", "matte_directional")]:
+            test_matches_oracle(gpu, port, name, world, params)
+        w = util.mesh_tunnel_scene(96, 72)
+        test_matches_oracle(gpu, port, "mesh_tunnel", w, w.params(seed=5))
+    finally:
+        del os.environ["RT_DEBUG"]
 
 
 @pytest.mark.gpu
