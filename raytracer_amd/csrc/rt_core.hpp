@@ -598,16 +598,26 @@ RT_FN GateNode load_gate(const DScene& S, uint32_t i)
 
 // The gate array's leading run of top-level Plane nodes (the room of the reference's scenes), read from the kernel
 // arguments in a wave-uniform loop (DScene::lead_planes).  Returns the index of the first node after them.
-RT_FN uint32_t lead_planes_hit(const DScene& S, f3 o, f3 d, Hit& best)
+// An axis plane that cannot become the closest hit is dropped before the IEEE division (6 per ray otherwise, for one
+// winner): with the approximate reciprocal of d[a] that the ray's gate constants hold (relative error <= 2^-22), the
+// approximate parameter decides when it is negative or beyond the best hit by a margin of 16x that error; everything
+// else — the candidates, parameters near 0, a best hit that is not positive — takes the exact evaluation.
+RT_FN bool plane_axis_cannot_win(float pa, float oa, float inv_da, float tbest)
+{
+    const float ta = (pa - oa) * inv_da;
+    return (ta < -1e-30f) || (tbest > 1e-30f && ta > tbest * 1.000004f + 1e-30f);
+}
+
+RT_FN uint32_t lead_planes_hit(const DScene& S, f3 o, f3 d, const RayGate& rg, Hit& best)
 {
     for (uint32_t j = 0; j < S.num_lead_planes; ++j) {
         const float* pl = S.lead_planes[j];
         float t;
         bool hit;
         switch ((S.lead_axis >> (4u * j)) & 15u) {   // wave-uniform
-        case 0: hit = plane_axis_t(pl[0], o.x, d.x, t); break;
-        case 1: hit = plane_axis_t(pl[1], o.y, d.y, t); break;
-        case 2: hit = plane_axis_t(pl[2], o.z, d.z, t); break;
+        case 0: hit = !plane_axis_cannot_win(pl[0], o.x, rg.ix, best.t) && plane_axis_t(pl[0], o.x, d.x, t); break;
+        case 1: hit = !plane_axis_cannot_win(pl[1], o.y, rg.iy, best.t) && plane_axis_t(pl[1], o.y, d.y, t); break;
+        case 2: hit = !plane_axis_cannot_win(pl[2], o.z, rg.iz, best.t) && plane_axis_t(pl[2], o.z, d.z, t); break;
         default: hit = plane_t(F3(pl[0], pl[1], pl[2]), F3(pl[3], pl[4], pl[5]), o, d, t); break;
         }
         if (hit && closer(t, f2u(pl[6]), best)) {
@@ -702,7 +712,7 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
     uint32_t cur_item = 0;
     uint32_t i = 0, sp = 0;
     const uint32_t n = S.num_gates;
-    if (MODE == 0) i = lead_planes_hit(S, o, d, best);   // the shadow query keeps per-entry state: it walks these nodes like any other
+    if (MODE == 0) i = lead_planes_hit(S, o, d, rg, best);   // the shadow query keeps per-entry state: it walks these nodes like any other
     while (i < n) {
         const GateNode g = load_gate(S, i);
         if (MODE == 1 && g.item != cur_item) {

@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_ao_walk(DScene S, RenderArgs A, Ba
                     dst = slot_ao * n2 + k;
                     rg = make_gate(S.cull_pad, S.extent, o, dir);
                     h.t = S.ambient.occlusion_dist; h.prim = H_MISS; h.rank = 0;
-                    i = (S.debug & 2u) ? ng : lead_planes_hit(S, o, dir, h);
+                    i = (S.debug & 2u) ? ng : lead_planes_hit(S, o, dir, rg, h);
                     sp = 0;
                     active = true;
                 }

@@ -250,7 +250,7 @@ RT_FN void trace_item(const DScene& S, const RenderArgs& A, const Batch& B, int 
         o = xyz(o4); d = xyz(d4);
         if (!(S.debug & 2u)) {
             const RayGate rg = make_gate(S.cull_pad, S.extent, o, d);
-            uint32_t i = lead_planes_hit(S, o, d, h);
+            uint32_t i = lead_planes_hit(S, o, d, rg, h);
             i = walk_gates<STATS>(S, o, d, rg, i, h, st, sp, cnt);
             if (i < S.num_gates) { overflow = true; sp = 0; }   // more Meshes than one item carries
         }
@@ -516,7 +516,7 @@ RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int dep
             dir = ao_dir(S.ambient, xyz(ru), xyz(rw), f2u(ro.w), f2u(rw.w), k);
             dst = slot * (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples) + k;
             rg = make_gate(S.cull_pad, S.extent, o, dir);
-            i = (S.debug & 2u) ? S.num_gates : lead_planes_hit(S, o, dir, h);
+            i = (S.debug & 2u) ? S.num_gates : lead_planes_hit(S, o, dir, rg, h);
         }
     }
     for (;;) {
