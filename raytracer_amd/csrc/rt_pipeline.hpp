@@ -473,7 +473,8 @@ RT_FN void shadow_overflow_item(const DScene& S, const RenderArgs& A, const Batc
     if (entry + lane < n) shadow_item<STATS>(S, A, B, depth, entry + lane, st, cnt);
 }
 
-// AO work item -> (slot, stratum k).  Blocked stratum-major order: RT_AO_BLOCK consecutive slots x all n*n
+// AO work item -> (slot, stratum k) for the refilling walk kernel (k_ao_walk, GPU), whose items are single rays.
+// Blocked stratum-major order: RT_AO_BLOCK consecutive slots x all n*n
 // strata, stratum by stratum, so a wave traces the same stratum (x,y) of 64 neighbouring hits, whose rays leave
 // nearby points in similar directions, and the 16 passes over a block's hit records (~70 B each) are served by L2.
 // item = base + off with base a multiple of 256 that is the same for the whole workgroup (GPU) and off < 256:
@@ -491,69 +492,77 @@ RT_FN void ao_coords(const DScene& S, uint32_t nslots, uint32_t base, uint32_t o
     }
 }
 
-// One AO ray (Ambient::L's inner loop, main.cpp:1372-1398).  The hot kernel traverses nothing: it walks the gate
-// nodes, tests planes / spheres / free triangles in place and queues the triangle-BVH roots of the Meshes whose
-// gates pass for k_bvh — one queue item per RT_DEFER_ROOTS roots, as many items as the ray needs.  All of a ray's
-// distances (its own and its items') meet in ao_key[dst] by minimum.  A wave that finds the queue full sets
-// `overflow`: its 64 rays are redone by ao_overflow_item.
+// ao_key index of the distance of stratum k of the path in AO slot `slot`: stratum-major, so that the 64 lanes of a
+// wave (64 consecutive slots, one stratum at a time) store and k_shade loads contiguous words.
+RT_FN size_t ao_index(const Batch& B, uint32_t slot, uint32_t k) { return (size_t)k * B.P + slot; }
+
+// The n*n AO rays of one hit (Ambient::L's loop, main.cpp:1372-1398).  One lane = one AO slot, all its strata in
+// turn: the AO frame is read once per hit, and at any time the lanes of a wave trace the SAME stratum of 64
+// neighbouring hits, i.e. similar rays.  The hot kernel traverses nothing: it walks the gate nodes, tests planes /
+// spheres / free triangles in place and queues the triangle-BVH roots of the Meshes whose gates pass for k_bvh —
+// one queue item per RT_DEFER_ROOTS roots, as many items as the ray needs.  All of a ray's distances (its own and
+// its items') meet in ao_key by minimum.  A wave that finds the queue full sets `overflow`: all rays of its 64
+// slots are redone by ao_overflow_item.
 // GPU: called by all 64 lanes of a wave (`valid` = false for lanes without an item): the queue cursor votes.
 template <bool STATS>
-RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t base, uint32_t off, uint32_t nslots, bool valid, Stack st,
+RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t slot, bool valid, Stack st,
                    Counters& cnt, QCursor& qc, bool& overflow)
 {
-    f3 o = F3(0, 0, 0), dir = F3(0, 0, 1);
-    Hit h; h.t = S.ambient.occlusion_dist; h.prim = H_MISS; h.u = 0; h.v = 0; h.rank = 0;
-    uint32_t dst = 0, sp = 0, slot = 0, k = 0, i = S.num_gates;
-    RayGate rg = {};
-    if (valid) {   // slot = position of the path in this depth's path list; paths without AO rays hold no path id
-        ao_coords(S, nslots, base, off, slot, k);
-        const q4 rw = B.ao_w[slot];
-        valid = f2u(rw.w) != 0xFFFFFFFFu;
+    const uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
+    // slot = position of the path in this depth's path list; paths without AO rays hold no path id
+    if (valid) valid = f2u(B.ao_w[slot].w) != 0xFFFFFFFFu;
+    for (uint32_t k = 0; k < n2; ++k) {   // wave-uniform
+        f3 o = F3(0, 0, 0), dir = F3(0, 0, 1);
+        Hit h; h.t = S.ambient.occlusion_dist; h.prim = H_MISS; h.u = 0; h.v = 0; h.rank = 0;
+        uint32_t sp = 0, i = S.num_gates;
+        const uint32_t dst = (uint32_t)ao_index(B, slot, k);
+        RayGate rg = {};
         if (valid) {
-            const q4 ro = B.ao_o[slot], ru = B.ao_u[slot];
+            // the frame is re-read for every stratum (48 bytes, served by the vector L1 after the first): keeping it in
+            // registers across the walk costs the kernel a wave of occupancy
+            const q4 ro = B.ao_o[slot], ru = B.ao_u[slot], rw = B.ao_w[slot];
             cnt.rays++;
             o = xyz(ro);
             dir = ao_dir(S.ambient, xyz(ru), xyz(rw), f2u(ro.w), f2u(rw.w), k);
-            dst = slot * (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples) + k;
             rg = make_gate(S.cull_pad, S.extent, o, dir);
             i = (S.debug & 2u) ? S.num_gates : lead_planes_hit(S, o, dir, rg, h);
         }
-    }
-    for (;;) {
-        if (i < S.num_gates) i = walk_gates<STATS>(S, o, dir, rg, i, h, st, sp, cnt);
-        const bool want = sp > 0;
-        const uint32_t item = chunk_append<RT_QCHUNK>(&B.counters[C_BQA + depth], want, qc, B.bq_roots, (uint32_t)REF_NONE, B.bq_cap);
-        if (want) {
-            if (item < B.bq_cap) {
-                const q4 a = {o.x, o.y, o.z, h.t};   // an upper bound of the ray's distance: the minimum is taken at the destination
-                const q4 b = {dir.x, dir.y, dir.z, u2f(dst | ((sp - 1u) << 29))};   // dst < 2^29 (checked where the batch is sized); 1 <= sp <= RT_DEFER_ROOTS
-                B.bq_a[item] = a; B.bq_b[item] = b;
-                for (uint32_t r = 0; r < sp; ++r) B.bq_roots[(size_t)r * B.bq_cap + item] = st.p[r * st.stride];
-            } else overflow = true;
-            sp = 0;
+        for (;;) {
+            if (i < S.num_gates) i = walk_gates<STATS>(S, o, dir, rg, i, h, st, sp, cnt);
+            const bool want = sp > 0;
+            const uint32_t item = chunk_append<RT_QCHUNK>(&B.counters[C_BQA + depth], want, qc, B.bq_roots, (uint32_t)REF_NONE, B.bq_cap);
+            if (want) {
+                if (item < B.bq_cap) {
+                    const q4 a = {o.x, o.y, o.z, h.t};   // an upper bound of the ray's distance: the minimum is taken at the destination
+                    const q4 b = {dir.x, dir.y, dir.z, u2f(dst | ((sp - 1u) << 29))};   // dst < 2^29 (checked where the batch is sized); 1 <= sp <= RT_DEFER_ROOTS
+                    B.bq_a[item] = a; B.bq_b[item] = b;
+                    for (uint32_t r = 0; r < sp; ++r) B.bq_roots[(size_t)r * B.bq_cap + item] = st.p[r * st.stride];
+                } else overflow = true;
+                sp = 0;
+            }
+            if (!wave_any(i < S.num_gates)) break;
         }
-        if (!wave_any(i < S.num_gates)) break;
+        if (valid) B.ao_key[dst] = t_key(h.t);   // stays occlusion_dist when nothing closer was found
     }
-    if (valid) B.ao_key[dst] = t_key(h.t);   // stays occlusion_dist when nothing closer was found
 }
 
-// The rays of a wave of ao_item that found the queue full, each traversed in place, start to end (the queue is
-// sized so that this does not happen with the reference's scenes; tests force it).  `entry` = the wave's first item.
+// The rays of 64 AO slots whose wave found the queue full, each traversed in place, start to end (the queue is
+// sized so that this does not happen with the reference's scenes; tests force it).  `entry` = the first slot.
 template <bool STATS>
 RT_FN void ao_overflow_item(const DScene& S, const RenderArgs& A, const Batch& B, uint32_t entry, uint32_t lane, uint32_t nslots, Stack st, Counters& cnt)
 {
     const uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
-    const uint32_t base = entry & ~255u, off = (entry & 255u) + lane;
-    if ((uint64_t)base + off >= (uint64_t)nslots * n2) return;
-    uint32_t slot, k;
-    ao_coords(S, nslots, base, off, slot, k);
+    const uint32_t slot = entry + lane;
+    if (slot >= nslots) return;
     const q4 rw = B.ao_w[slot];
     if (f2u(rw.w) == 0xFFFFFFFFu) return;
     const q4 ro = B.ao_o[slot], ru = B.ao_u[slot];
-    const f3 o = xyz(ro), dir = ao_dir(S.ambient, xyz(ru), xyz(rw), f2u(ro.w), f2u(rw.w), k);
-    Hit h; float sh;
-    trace<0, STATS, false>(S, o, dir, S.ambient.occlusion_dist, h, sh, st, cnt);
-    key_min(&B.ao_key[slot * n2 + k], t_key(h.t));
+    for (uint32_t k = 0; k < n2; ++k) {
+        const f3 dir = ao_dir(S.ambient, xyz(ru), xyz(rw), f2u(ro.w), f2u(rw.w), k);
+        Hit h; float sh;
+        trace<0, STATS, false>(S, xyz(ro), dir, S.ambient.occlusion_dist, h, sh, st, cnt);
+        key_min(&B.ao_key[ao_index(B, slot, k)], t_key(h.t));
+    }
 }
 
 // world->ambient->L(sr): Light::L, or Ambient::L's reduction of the n*n distances in x,y order
@@ -568,15 +577,7 @@ RT_FN f3 ambient_L(const DScene& S, const Batch& B, uint32_t p)
     float dist = A.occlusion_dist;
     float maxSum = (dist * (float)n * (float)n);
     float occluded = maxSum;
-    const uint32_t* t = B.ao_key + (size_t)slot * n * n;
-    if (n == 4) {   // the reference's setting: four 16-byte loads in flight, then the same sequential sum
-        const q4* t4 = reinterpret_cast<const q4*>(t);   // slot * 16 keys: 64-byte aligned
-        const q4 a = t4[0], b = t4[1], c = t4[2], e = t4[3];
-        const float v[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, e.x, e.y, e.z, e.w};
-        for (int k = 0; k < 16; ++k) occluded -= (dist - key_t(f2u(v[k])));
-    } else {
-        for (unsigned k = 0; k < n * n; ++k) occluded -= (dist - key_t(t[k]));
-    }
+    for (unsigned k = 0; k < n * n; ++k) occluded -= (dist - key_t(B.ao_key[ao_index(B, slot, k)]));   // x,y order = stratum order
     float f = occluded / maxSum;
     return base * f * f;
 }

@@ -65,13 +65,11 @@ struct LoopBackend {
     }
     void ao(const RenderArgs& A, int d, uint32_t fixed) {
         Stack st{stack.data(), 1};
-        uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
         QCursor qc{0, 0};
-        const uint32_t nslots = count(d, fixed);
-        for (uint32_t i = 0, n = nslots * n2; i < n; ++i) {
+        for (uint32_t slot = 0, nslots = count(d, fixed); slot < nslots; ++slot) {
             bool overflow = false;
-            ao_item<true>(S, A, B, d, i & ~255u, i & 255u, nslots, true, st, cnt[2], qc, overflow);
-            if (overflow) B.ao_ovf[B.counters[C_AO + d]++] = i;   // a "wave" of one lane
+            ao_item<true>(S, A, B, d, slot, true, st, cnt[2], qc, overflow);
+            if (overflow) B.ao_ovf[B.counters[C_AO + d]++] = slot;   // a "wave" of one lane
         }
     }
     void ao_overflow(const RenderArgs& A, int d, uint32_t fixed) {
