@@ -164,16 +164,17 @@ def main():
             extra = {"nodes_per_ray": round(V, 2), "tris_per_ray": round(T, 2), "ao_rays_total": int(ao_rays), "ao_rays_needing_bvh": int(units)}
             limiter = "valu-issue, then cache-served gathers (working set in L2/MALL; see profiles/*_pmc.csv and DESIGN.md 4)"
         else:
-            # config 5: the gate walk of the AO rays (k_ao) dominates: per ray the 48-byte AO frame, G 48-byte gate
+            # config 5: the gate walk of the AO rays (k_ao_walk) dominates: per ray the 48-byte AO frame, G 48-byte gate
             # nodes of the reference's shape-level hierarchy (G from the counting pass, LDS-staged ones included),
             # one 64-byte queue item per ray that reaches a mesh, 4 bytes of result.
-            kname, k = "k_ao", capi.RT_K_NAMES.index("ao")
+            kname, k = "k_ao_walk", capi.RT_K_NAMES.index("ao")
             units = ao_rays
             G = st_count.gates[2] / max(1.0, units)
             share = st_count.bvh_rays[2] / max(1.0, units)
             b_ray = 48.0 + 48.0 * G + 64.0 * share + 4.0
             extra = {"gates_per_ray": round(G, 2), "queued_share": round(share, 3), "ao_rays_total": int(ao_rays)}
-            limiter = "dependent 48-byte gate-node gathers + exact box tests (latency / VALU), not HBM"
+            limiter = ("texture-address / L1 path: three 16-byte gathers per lane and gate node out of L2 (TA busy 77 %, profiles/r02b5_pmc.csv); "
+                       "the 360-KB gate array never leaves L2, so the algorithmic bytes are cache-served and frac exceeds 1 - HBM does not bind")
         k_ms = kernel_ms[k] / args.steps
         k_launches = launches[k] / args.steps / (2.0 if k == capi.RT_K_NAMES.index("ao") else 1.0)   # the 'ao' class also times the (empty) overflow launch
         achieved = (units * b_ray) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
