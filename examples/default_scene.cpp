@@ -4,9 +4,10 @@
 // World, a BVHAccel over 12 shapes, a ThreadPool, 40x40 tile jobs calling raytrace(), waitDone(),
 // saveToFile("raytrace.bmp").
 //
-//   default_scene <modelRoot> [out.bmp] [width] [height]
+//   default_scene <modelRoot> [out.bmp] [width] [height] [whole | bbox]
 // <modelRoot>/teapot/teapot.obj (+ .mtl + texture) is the mesh; the reference's teapot.obj is not in
 // its repository, tests/test_host_cpp.py writes the procedural stand-in used everywhere in this repo.
+#include <cstdio>
 #include <cstdlib>
 #include <iostream>
 
@@ -67,6 +68,17 @@ int main(int argc, char** argv)
     auto multiMesh2 = std::make_shared<MultiMesh>(teapotObjMesh.value(), "teapot", Vector{-430, -100, 400});
     auto multiMesh3 = std::make_shared<MultiMesh>(teapotObjMesh.value(), "teapot", Vector{-150, 500, 200});
 
+    if (argc > 5 && std::string(argv[5]) == "bbox") {   // what the script hands to addShape, bit for bit (no GPU involved)
+        auto dump = [](const char* name, std::vector<Point> const& pts) {
+            std::printf("%s", name);
+            for (auto const& p : pts) std::printf(" %a %a %a", (double)p.x, (double)p.y, (double)p.z);
+            std::printf("\n");
+        };
+        for (auto& s : {sphere1, sphere2, sphere3, sphere4, sphere5, sphere6, sphere7}) dump("sphere", s->getBoundingBoxPoints());
+        dump("triangle", triangle1->getBoundingBoxPoints()); dump("triangle", triangle2->getBoundingBoxPoints());
+        for (auto& m : {multiMesh1, multiMesh2, multiMesh3}) dump("multimesh", m->getBoundingBoxPoints());
+        return 0;
+    }
     bvhAccel->addShape(triangle1->getBoundingBoxPoints(), triangle1);
     bvhAccel->addShape(triangle2->getBoundingBoxPoints(), triangle2);
     bvhAccel->addShape(multiMesh1->getBoundingBoxPoints(), multiMesh1);

@@ -109,6 +109,7 @@ class RefOracle(_Base):
         L.ref_bvh_dump.argtypes = [C.POINTER(capi.rt_scene_desc), C.POINTER(capi.rt_params), C.c_char_p,
                                    C.c_uint32, C.c_void_p, C.c_int]
         L.ref_save_bmp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
+        L.ref_bbox_points.argtypes = [C.POINTER(capi.rt_scene_desc), C.POINTER(capi.rt_params), C.c_char_p, C.c_int, C.c_uint32, fp]
 
     def save_bmp_bytes(self, rgb):
         """The bytes the reference's saveToFile (main.cpp:1837-1857, stbi_write_bmp) writes for rgb[H,W,3]."""
@@ -119,6 +120,15 @@ class RefOracle(_Base):
             raise RuntimeError("ref_save_bmp failed")
         with open(path, "rb") as f:
             return f.read()
+
+    def bbox_points(self, flat, params, kind, index):
+        """The reference's getBoundingBoxPoints() of one shape: float32 [6, 3]."""
+        out = np.zeros((6, 3), np.float32)
+        n = self.lib.ref_bbox_points(C.byref(flat.desc), C.byref(params), self._tmp.encode(), kind, index,
+                                     out.ctypes.data_as(C.POINTER(C.c_float)))
+        if n != 6:
+            raise RuntimeError("ref_bbox_points failed")
+        return out
 
     def bvh_dump(self, flat, params, which=0, cap=4096):
         out = np.zeros((cap, 9), np.float32)

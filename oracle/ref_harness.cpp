@@ -579,6 +579,24 @@ int ref_save_bmp(const float* rgb, int width, int height, const char* path)
     return 0;
 }
 
+// getBoundingBoxPoints() of shape #index of the given kind (RT_SHAPE_SPHERE / TRIANGLE / MESH / MULTIMESH): the six
+// support points x-, x+, y-, y+, z-, z+ (main.cpp:303-313) -> out[18].  Returns the number of points (6), < 0 on error.
+int ref_bbox_points(const rt_scene_desc* d, const rt_params* p, const char* tmpdir, int kind, uint32_t index, float* out)
+{
+    Built b;
+    if (!build_world(*d, *p, tmpdir ? tmpdir : "/tmp/ref_oracle_tmp", b)) { g_err = b.error; return -1; }
+    std::vector<Point> pts;
+    switch (kind) {
+    case RT_SHAPE_SPHERE: if (index >= b.spheres.size()) return -1; pts = b.spheres[index]->getBoundingBoxPoints(); break;
+    case RT_SHAPE_TRIANGLE: if (index >= b.tris.size() || !b.tris[index]) return -1; pts = b.tris[index]->getBoundingBoxPoints(); break;
+    case RT_SHAPE_MESH: if (index >= b.meshes.size() || !b.meshes[index]) return -1; pts = b.meshes[index]->getBoundingBoxPoints(); break;
+    case RT_SHAPE_MULTIMESH: if (index >= b.multimeshes.size()) return -1; pts = b.multimeshes[index]->getBoundingBoxPoints(); break;
+    default: return -1;
+    }
+    for (size_t i = 0; i < pts.size() && i < 6; ++i) { out[i * 3] = pts[i].x; out[i * 3 + 1] = pts[i].y; out[i * 3 + 2] = pts[i].z; }
+    return (int)pts.size();
+}
+
 // BVHAccel hierarchy dump for a desc's bvh #which: per node {leaf, left, right, min[3], max[3]}
 int ref_bvh_dump(const rt_scene_desc* d, const rt_params* p, const char* tmpdir, uint32_t which, float* out, int cap_nodes)
 {

@@ -221,6 +221,25 @@ Mesh::Mesh(atlas::utils::Shape const& shape, unsigned int matIndex, std::vector<
     }
 }
 
+std::vector<Point> Mesh::getBoundingBoxPoints() const
+{
+    if (mTriangles.empty()) return {};
+    auto pt = [](const float* v) { return Point{v[0], v[1], v[2]}; };
+    BoundingVolumeBox b(pt(mTriangles[0].v0));
+    for (const rt_triangle& t : mTriangles) { b.addVolumePoint(pt(t.v0)); b.addVolumePoint(pt(t.v1)); b.addVolumePoint(pt(t.v2)); }
+    return b.getBoundingBoxPoints();
+}
+
+std::vector<Point> MultiMesh::getBoundingBoxPoints() const
+{
+    if (meshes.empty()) return {};
+    const std::vector<Point> first = meshes[0].getBoundingBoxPoints();
+    if (first.empty()) return {};
+    BoundingVolumeBox b(first[0]);
+    for (const Mesh& m : meshes) for (const Point& q : m.getBoundingBoxPoints()) b.addVolumePoint(q);
+    return b.getBoundingBoxPoints();
+}
+
 MultiMesh::MultiMesh(atlas::utils::ObjMesh const& mesh, std::string modelSubDirName, Vector offset)
 {
     std::vector<std::shared_ptr<Textured>> loaded;

@@ -248,17 +248,49 @@ public:
     std::shared_ptr<Material> getMaterial() const { return mMaterial; }
     Colour mColour; std::shared_ptr<Material> mMaterial;
 };
+// The six support points of an axis-aligned box (reference main.cpp:190-226, 303-313): a point replaces the
+// support point of a side only when it lies strictly beyond it, and getBoundingBoxPoints() lists them in the order
+// x-, x+, y-, y+, z-, z+.  Scripts pass these lists to BVHAccel::addShape; the GPU path rebuilds every box from the
+// geometry at rt_scene_commit, so they are bookkeeping for scripts that look at them.
+class BoundingVolumeBox {
+public:
+    explicit BoundingVolumeBox(Vector const& startPoint) { for (auto& p : mP) p = startPoint; }
+    void addVolumePoint(Point const& q)
+    {
+        if (q.x < mP[0].x) mP[0] = q;
+        if (q.x > mP[1].x) mP[1] = q;
+        if (q.y < mP[2].y) mP[2] = q;
+        if (q.y > mP[3].y) mP[3] = q;
+        if (q.z < mP[4].z) mP[4] = q;
+        if (q.z > mP[5].z) mP[5] = q;
+    }
+    Point getCentroid() const { return {(mP[0].x + mP[1].x) / 2.0f, (mP[2].y + mP[3].y) / 2.0f, (mP[4].z + mP[5].z) / 2.0f}; }
+    std::vector<Point> getBoundingBoxPoints() const { return {mP[0], mP[1], mP[2], mP[3], mP[4], mP[5]}; }
+private:
+    Point mP[6];
+};
+
 class Sphere : public Shape {
 public:
     Sphere(Point center, float radius) : mCentre(center), mRadius(radius) {}
-    std::vector<Point> getBoundingBoxPoints() { return {}; }   // boxes are rebuilt by rt_scene_commit
+    std::vector<Point> getBoundingBoxPoints()   // main.cpp:571-576
+    {
+        BoundingVolumeBox b(Point{mCentre.x + mRadius, mCentre.y + mRadius, mCentre.z + mRadius});
+        b.addVolumePoint(Point{mCentre.x - mRadius, mCentre.y - mRadius, mCentre.z - mRadius});
+        return b.getBoundingBoxPoints();
+    }
     Point mCentre; float mRadius;
 };
 class Triangle : public Shape {
 public:
     Triangle(Point p0, Point p1, Point p2, Vector2 p0UV = {0, 0}, Vector2 p1UV = {0, 0}, Vector2 p2UV = {0, 0})
         : mV0(p0), mV1(p1), mV2(p2), mUV0(p0UV), mUV1(p1UV), mUV2(p2UV) {}
-    std::vector<Point> getBoundingBoxPoints() { return {}; }
+    std::vector<Point> getBoundingBoxPoints()   // main.cpp:705-711
+    {
+        BoundingVolumeBox b(mV0);
+        b.addVolumePoint(mV1); b.addVolumePoint(mV2);
+        return b.getBoundingBoxPoints();
+    }
     Point mV0, mV1, mV2; Vector2 mUV0, mUV1, mUV2;
 };
 class Plane : public Shape {
@@ -270,19 +302,19 @@ class Mesh : public Shape {   // one OBJ shape, vertices translated by `offset` 
 public:
     Mesh(atlas::utils::Shape const& shape, unsigned int matIndex, std::vector<std::shared_ptr<Textured>> const& loadedMaterials,
          std::string modelSubDirName, Vector offset = {0, 0, 0});
-    std::vector<Point> getBoundingBoxPoints() { return {}; }
+    std::vector<Point> getBoundingBoxPoints() const;   // main.cpp:875-886: v0, then every triangle's v0, v1, v2
     std::vector<rt_triangle> mTriangles;   // material filled at flatten time
 };
 class MultiMesh : public Shape {
 public:
     MultiMesh(atlas::utils::ObjMesh const& mesh, std::string modelSubDirName = "", Vector offset = {0, 0, 0});
-    std::vector<Point> getBoundingBoxPoints() { return {}; }
+    std::vector<Point> getBoundingBoxPoints() const;   // main.cpp:757-765, 798-801: over the support points of its meshes
     std::vector<Mesh> meshes;
 };
 class BVHAccel : public Shape {
 public:
     void addShape(std::vector<Point>, std::shared_ptr<Shape> shape) { mLeaves.push_back(std::move(shape)); }
-    void generateBVH() {}   // the hierarchy is rebuilt by rt_scene_commit with the reference's algorithm
+    void generateBVH() {}   // the hierarchy is rebuilt by rt_scene_commit with the reference's algorithm (from the shapes, not from the point lists)
     std::vector<std::shared_ptr<Shape>> mLeaves;
 };
 

@@ -113,8 +113,33 @@ def cpp_host(ref):
     print("cpp_host fixture", r.rgb.shape, "rays", r.rays)
 
 
+def bbox(ref):
+    """getBoundingBoxPoints() of the shapes of the reference's main() scene (7 spheres, 2 free triangles, 3
+    MultiMeshes of the stand-in mesh), as the REAL reference computes them: what the C++ drop-in's
+    getBoundingBoxPoints() must return (examples/default_scene <models> - - - bbox)."""
+    from raytracer_amd import scenes, scene as S, capi
+    w = scenes.default_scene(160, 120, sampler=S.Jitter(4, 83), ao_samples=4)
+    flat = w.flatten()
+    p = w.params(seed=1)
+    d = flat.desc
+    out = {
+        "spheres": np.stack([ref.bbox_points(flat, p, capi.RT_SHAPE_SPHERE, i) for i in range(d.num_spheres)]),
+        "multimeshes": np.stack([ref.bbox_points(flat, p, capi.RT_SHAPE_MULTIMESH, i) for i in range(d.num_multimeshes)]),
+    }
+    in_mesh = np.zeros(d.num_triangles, bool)
+    for m in flat.arrays["meshes"]:
+        in_mesh[int(m["first_triangle"]): int(m["first_triangle"]) + int(m["num_triangles"])] = True
+    tri_ids = [int(i) for i in np.flatnonzero(~in_mesh)]
+    out["triangles"] = np.stack([ref.bbox_points(flat, p, capi.RT_SHAPE_TRIANGLE, i) for i in tri_ids])
+    np.savez_compressed(os.path.join(HERE, "bbox_points.npz"), **out)
+    print("bbox fixture", {k: v.shape for k, v in out.items()})
+
+
 def main():
     ref = RefOracle()
+    if sys.argv[1:] == ["bbox"]:
+        bbox(ref)
+        return
     if sys.argv[1:] == ["cpp_host"]:
         cpp_host(ref)
         return

@@ -51,6 +51,25 @@ def test_example_is_built():
     assert os.path.exists(EXE)
 
 
+def test_bounding_box_points_equal_the_reference(tmp_path):
+    """Sphere / Triangle / MultiMesh::getBoundingBoxPoints() of the drop-in header (the lists a scene script hands to
+    BVHAccel::addShape) against tests/golden/bbox_points.npz, the REAL reference's values for the shapes of its
+    main() scene (make_golden.py bbox): bit-identical, in the reference's order x-, x+, y-, y+, z-, z+.  No GPU."""
+    test_example_is_built()
+    g = np.load(os.path.join(util.GOLDEN, "bbox_points.npz"))
+    write_model_dir(str(tmp_path))
+    r = subprocess.run([EXE, str(tmp_path), "-", "160", "120", "bbox"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = {"sphere": [], "triangle": [], "multimesh": []}
+    for line in r.stdout.splitlines():
+        name, *vals = line.split()
+        got[name].append(np.array([float.fromhex(v) for v in vals], np.float32).reshape(6, 3))
+    for name, key in (("sphere", "spheres"), ("triangle", "triangles"), ("multimesh", "multimeshes")):
+        mine = np.stack(got[name])
+        assert mine.shape == g[key].shape
+        assert np.array_equal(mine.view(np.uint32), g[key].view(np.uint32)), name
+
+
 @pytest.mark.gpu
 def test_cpp_scene_script_matches_the_reference_render(tmp_path):
     """SURVEY 8f N3 + N4 end to end: examples/default_scene.cpp = the reference's main() scene script compiled
