@@ -208,6 +208,29 @@ def test_full_size_crop_against_oracle(port, config3_full):
 
 
 @pytest.mark.gpu
+def test_config5_full_scale_crop_against_oracle(gpu, port):
+    """BASELINE config 5 at its stated scale — 2500 instanced meshes = 10.24 M triangles behind the reference's
+    shape-level BVHAccel (7500 gate nodes: k_ao_walk, k_shadow_defer and the overflow kernels all run), 1920x1080
+    geometry, 4x4 AO — on a 24x24 crop in the middle of the instance field against the CPU oracle, which scans every
+    triangle of every mesh whose gates pass (a crop is what it can afford): primitive ids and ray parameters
+    bit-identical, RGB within 1 LSB."""
+    from raytracer_amd import scenes
+    world = scenes.config5_scene(1920, 1080, 1, instances=2500)
+    flat = world.flatten()
+    params = world.params(seed=3)
+    q = capi.rt_params.from_buffer_copy(params)
+    q.x0, q.x1, q.y0, q.y1 = 948, 972, 600, 624
+    gpu.upload(flat)
+    rgb, prim, t, st = gpu.render(world.camera, q, ids=True)
+    want = port.render(flat, world.camera, q, rng_mode=1, nthreads=16)
+    sl = (slice(q.y0, q.y1), slice(q.x0, q.x1))
+    assert (want.primid[sl] != capi.RT_MISS).mean() > 0.5, "the crop should look at the instances"
+    assert np.array_equal(prim[sl], want.primid[sl])
+    assert util.bits_equal(t[sl], want.t[sl])
+    assert util.lsb_diff(rgb[sl], want.rgb[sl]).max() <= 1
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("debug", ["8", "24"])
 def test_bvh_queue_overflow_falls_back_inline(gpu, debug):
     """RT_DEBUG=8 (read at rt_scene_commit) caps the compacted BVH queue at 3000 items, so most
