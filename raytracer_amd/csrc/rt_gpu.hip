@@ -521,10 +521,7 @@ struct GpuBackend {
     {
         hipError_t r = hipMemsetAsync(B.counters, 0, sizeof(uint32_t) * C_TOTAL, stream);
         if (r != hipSuccess) err = r;
-        if (walk_refill) {
-            r = hipMemsetAsync(B.ovf_bits, 0, ovf_bits_bytes, stream);
-            if (r != hipSuccess) err = r;
-        }
+
     }
     void raygen(const RenderArgs& A, uint32_t n) { timed(RT_K_RAYGEN, [&] { hipLaunchKernelGGL(k_raygen, dim3(grid_for(n)), dim3(RT_BLOCK), 0, stream, S, A, B, n); }); }
     // many short blocks for the uneven kernels, but at least 16 items per thread (small frames: the per-block set-up
@@ -590,6 +587,9 @@ struct GpuBackend {
     {
         if (S.ambient.occlusion_samples <= 0) return;
         if (walk_refill) {   // many gate nodes: the refilling walk (k_ao_walk)
+            // its "group already entered in the overflow list" bits hold for ONE launch (one depth level of one batch)
+            hipError_t r = hipMemsetAsync(B.ovf_bits, 0, ovf_bits_bytes, stream);
+            if (r != hipSuccess) err = r;
             const uint32_t gw = grid_many((uint64_t)n * (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples), d == 0 ? RT_GRID_AO_WALK : RT_MAX_GRID);
             timed(RT_K_AO, [&] {
                 if (stats) hipLaunchKernelGGL(k_ao_walk<true>, dim3(gw), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);

@@ -253,6 +253,28 @@ def test_bvh_queue_overflow_falls_back_inline(gpu, debug):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("debug", ["8", "12", "24", "28"])
+def test_overflow_kernels_on_scenes_with_bounces(gpu, port, debug):
+    """The overflow kernels (RT_DEBUG bit 8: work queue capped at 3000 items) at EVERY depth level of scenes with
+    mirrors / refraction, with the inline shadow kernel (bit 4) and the refilling AO walk (bit 16) switched in:
+    random scenes that a fuzz campaign found when k_ao_walk kept its overflow-group bits from one depth level to
+    the next (tools/fuzz_gpu.py, seeds 40089 / 40403 / 40497)."""
+    import os
+    os.environ["RT_DEBUG"] = debug
+    try:
+        for seed in (40089, 40403, 40497):
+            w, params = util.random_scene(seed)
+            flat = w.flatten()
+            want = port.render(flat, w.camera, params, rng_mode=1, nthreads=8)
+            gpu.upload(flat)
+            rgb, prim, t, st = gpu.render(w.camera, params, ids=True)
+            assert np.array_equal(prim, want.primid) and util.bits_equal(t, want.t), seed
+            assert util.lsb_diff(rgb, want.rgb).max() <= 1, seed
+    finally:
+        del os.environ["RT_DEBUG"]
+
+
+@pytest.mark.gpu
 def test_refilling_gate_walk_matches_the_oracle(gpu, port):
     """k_ao_walk (the AO gate walk of scenes with more than 64 gate nodes, where lanes refill as their walks end)
     forced on small scenes by RT_DEBUG=16: against the oracle like every other case, incl. the scene whose rays cross
