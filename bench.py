@@ -188,7 +188,10 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "traffic_gbs": round(traffic / launch_s / 1e9, 1) if traffic and launch_s > 0 else None,
             "traffic_frac": round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic and launch_s > 0 else None,
-            "limiter": limiter, "bytes_per_ray": round(b_ray, 1),
+            "limiter": limiter,
+            "frac_note": ("achieved/frac price every algorithmic byte (SURVEY 8d) at HBM cost although caches serve most of them, so they can exceed 1; "
+                          "traffic_frac is the measured HBM share"),
+            "bytes_per_ray": round(b_ray, 1),
             "rays_per_launch": round(units / max(1.0, k_launches), 1), "avg_launch_ms": round(k_ms / max(1.0, k_launches), 4),
             "mrays_per_s_in_kernel": round(units / (k_ms * 1e-3) / 1e6, 1) if k_ms > 0 else None,
         }
