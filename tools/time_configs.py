@@ -23,6 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scale", type=int, default=4, help="divide each config's image size by this")
     ap.add_argument("--instances", type=int, default=2500)
+    ap.add_argument("--only", default=None, help="one of config1, config2, config4, config5")
     args = ap.parse_args()
     s = args.scale
     cases = [
@@ -31,6 +32,8 @@ def main():
         ("config4", lambda: scenes.config4_scene(3840 // s, 2160 // s, 16)),
         ("config5", lambda: scenes.config5_scene(7680 // (2 * s), 4320 // (2 * s), 4, instances=args.instances)),
     ]
+    if args.only:
+        cases = [c for c in cases if c[0] == args.only]
     dev = torch.device("cuda:0")
     r = Renderer(0)
     for name, make in cases:
@@ -60,6 +63,9 @@ def main():
             "rays": int(rays), "mrays_per_s": round(rays / ms / 1e3, 1),
             "kernel_ms": {n: round(float(st2.ms_kernel[i]), 2) for i, n in enumerate(capi.RT_K_NAMES)},
             "nodes_per_bvh_ray": [round(st.nodes[k] / max(1, st.bvh_rays[k]), 1) for k in (0, 2)],
+            "gates_per_ray": {"closest": round(st.gates[0] / max(1, st.rays_primary + st.rays_bounce), 2), "shadow": round(st.gates[1] / max(1, st.rays_shadow), 2),
+                              "ao": round(st.gates[2] / max(1, st.rays_ao), 2)},
+            "ao_rays": int(st.rays_ao), "ao_bvh_share": round(st.bvh_rays[2] / max(1, st.rays_ao), 3),
         }), flush=True)
     r.close()
 
