@@ -165,6 +165,13 @@ typedef struct rt_stats {
     double   ms_kernel[RT_K_COUNT];  /* RT_FLAG_TIMING: summed per kernel class              */
     uint32_t launches[RT_K_COUNT];
     uint32_t batches;
+    /* Closest-hit queries the reference traces (its unit: one `for obj in world->scene: obj->hit()` loop,
+     * main.cpp:1645-1648, 51-56, 1390-1393, 1457-1460, 1548-1551) that this path proves unnecessary and does
+     * not trace: the shadow ray of a light the surface faces away from (the reference calls shadowed() before
+     * it tests n.wi > 0, main.cpp:1227, 1281) and the n x n occlusion rays of a surface whose ka is 0
+     * (main.cpp:1497; the reference's mirror, main.cpp:1714).  rays_primary + rays_shadow + rays_ao + rays_bounce
+     * + rays_skipped == the reference's own query count for the same frame, exactly. */
+    uint64_t rays_skipped;
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

@@ -87,11 +87,18 @@ class rt_stats(C.Structure):
         ("nodes", C.c_uint64 * 3), ("tris", C.c_uint64 * 3), ("gates", C.c_uint64 * 3), ("bvh_rays", C.c_uint64 * 3),
         ("ms_total", C.c_double), ("ms_kernel", C.c_double * RT_K_COUNT),
         ("launches", C.c_uint32 * RT_K_COUNT), ("batches", C.c_uint32),
+        ("rays_skipped", C.c_uint64),
     ]
 
     @property
     def rays(self):
+        """closest-hit queries this path traced"""
         return self.rays_primary + self.rays_shadow + self.rays_ao + self.rays_bounce
+
+    @property
+    def rays_reference_unit(self):
+        """the reference's own query count for the same frame: what was traced + what was proven unnecessary"""
+        return self.rays + self.rays_skipped
 
 
 def default_params(width=1000, height=1000, num_samples=4, num_sets=83, sampler=RT_SAMPLER_JITTER,

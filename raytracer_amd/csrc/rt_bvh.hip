@@ -116,15 +116,20 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
                     const q4 a = B.bq_a[idx], b = B.bq_b[idx];
                     const uint32_t root0 = B.bq_roots[idx];   // REF_NONE marks a hole
                     o = xyz(a); d = xyz(b);
-                    const uint32_t nroots = (f2u(b.w) >> 29) + 1u;
-                    dst = f2u(b.w) & 0x1FFFFFFFu;
+                    const bool multi = (f2u(b.w) & RT_BQ_MULTI) != 0u;
+                    dst = f2u(b.w) & RT_BQ_DST_MASK;
                     best.t = a.w; best.prim = H_MISS; best.rank = 0; best.u = 0; best.v = 0;
                     if (!AO) { const q4 c = B.bq_c[idx]; best.prim = f2u(c.x); best.rank = f2u(c.y); best.u = c.z; best.v = c.w; }
                     rc = make_cull4(S, o, d);
                     sp = 0; npend = 0; tri_left = 0;
                     if (root0 != REF_NONE) {
                         push(sp, root0, -INFINITY);
-                        for (uint32_t k = 1; k < nroots; ++k) push(sp, B.bq_roots[(size_t)k * B.bq_cap + idx], -INFINITY);   // rare: one Mesh is the rule
+                        if (multi)   // rare: one Mesh is the rule; a list shorter than RT_DEFER_ROOTS ends with REF_NONE
+                            for (uint32_t k = 1; k < RT_DEFER_ROOTS; ++k) {
+                                const uint32_t rk = B.bq_roots[(size_t)k * B.bq_cap + idx];
+                                if (rk == REF_NONE) break;
+                                push(sp, rk, -INFINITY);
+                            }
                     }
                     if (sp > 0) { cur = pop(sp).x; active = true; if (STATS) nrays++; }   // a slot without roots is a hole
                 }

@@ -114,11 +114,14 @@ __global__ void __launch_bounds__(RT_BLOCK) k_prep(DScene S, RenderArgs A, Batch
     const uint32_t n = depth == 0 ? fixed_n : B.counters[C_QUEUE + depth];
     QCursor qsh{0, 0, queue_chunk((uint64_t)n * S.num_lights, gridDim.x * (RT_BLOCK / 64), RT_SHCHUNK)};
     // wave-uniform trip count: every lane of a wave takes part in the queue cursor's ballots
+    uint32_t skipped = 0;
     for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
         const uint32_t i = base + threadIdx.x;
-        prep_item(S, A, B, depth, i, i < n, qsh);
+        prep_item(S, A, B, depth, i, i < n, qsh, skipped);
     }
     close_cursor(qsh, B.sh_queue, 0xFFFFFFFFu, B.sh_cap);
+    for (int off = 32; off > 0; off >>= 1) skipped += __shfl_xor(skipped, off);
+    if ((threadIdx.x & 63u) == 0u && skipped) atomicAdd(&B.stats[ST_SKIPPED], (unsigned long long)skipped);
 }
 
 // k_shadow traverses inline, lane by lane: half-size blocks (2 waves) even out its uneven rays a little better (11.1 -> 10.3 ms)
@@ -263,9 +266,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_ao_walk(DScene S, RenderArgs A, Ba
         if (want) {
             if (slot < B.bq_cap) {
                 const q4 a = {o.x, o.y, o.z, h.t};
-                const q4 b = {dir.x, dir.y, dir.z, u2f(dst | ((sp - 1u) << 29))};
+                const q4 b = {dir.x, dir.y, dir.z, u2f(bq_word(dst, sp))};
                 B.bq_a[slot] = a; B.bq_b[slot] = b;
-                for (uint32_t r = 0; r < sp; ++r) B.bq_roots[(size_t)r * B.bq_cap + slot] = st.p[r * st.stride];
+                bq_store_roots(B, slot, st, sp);
             } else {   // queue full: all rays of the 64 AO slots around this ray's are redone by k_ao_overflow (entered once)
                 const uint32_t g = slot_of >> 6;
                 if (!(atomicOr(&B.ovf_bits[g >> 5], 1u << (g & 31u)) & (1u << (g & 31u)))) {
@@ -284,7 +287,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_ao_walk(DScene S, RenderArgs A, Ba
             if (lane == 0) b0 = atomicAdd(&B.counters[C_AOW + depth], (uint32_t)RT_WALK_CHUNK);
             b0 = __shfl(b0, 0);
             next = b0 < n ? b0 : n; end = b0 + RT_WALK_CHUNK < n ? b0 + RT_WALK_CHUNK : n;
-            exhausted = b0 >= n || n - b0 <= RT_WALK_CHUNK;   // n < 2^29: no wrap
+            exhausted = b0 >= n || n - b0 <= RT_WALK_CHUNK;   // n < 2^31: no wrap
         }
         if (next < end && nidle >= RT_WALK_REFILL) {
             const uint32_t mine = next + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
@@ -410,6 +413,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bmp24(const float* rgb, uint8_t* f
 static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
 #define RT_MAX_DEVICES 64
 static unsigned char* g_scratch_ptr[RT_MAX_DEVICES];   // per device, set by rt_init under g_scratch_mu
+// End of the last rt_render_device_noalloc call that used this device's array, on whatever context and stream it ran:
+// the next one waits for it on the device, so calls through different contexts of one GPU serialise instead of racing
+// (calls replayed from a captured graph are the caller's to order: nothing can be recorded for them here).
+static hipEvent_t g_scratch_ev[RT_MAX_DEVICES];
+static bool g_scratch_ev_recorded[RT_MAX_DEVICES];
 static std::mutex g_scratch_mu;
 
 // ---- context / scene objects ------------------------------------------------------------------------
@@ -434,6 +442,8 @@ struct rt_ctx {
     // one render at a time even when callers alternate streams.  ev_null: see order_after_null_stream().
     hipEvent_t ev_done = nullptr, ev_null = nullptr;
     bool done_recorded = false;
+    hipEvent_t ev_slab = nullptr;            // rt_render_multi: this rank's slab has landed on the gathering GPU
+    std::vector<int> peers_enabled;          // devices this context's device may write to directly (hipDeviceEnablePeerAccess done)
 };
 
 struct rt_scene {
@@ -705,6 +715,12 @@ int rt_init(int device, rt_ctx** out)
                 g_init_error = std::string("rt_init: hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
                 return RT_ERR_HIP;
             }
+            hipEvent_t ev = nullptr;
+            if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) {
+                g_init_error = std::string("rt_init: hipEventCreate(scratch): ") + hipGetErrorString(e);
+                return RT_ERR_HIP;
+            }
+            g_scratch_ev[device] = ev; g_scratch_ev_recorded[device] = false;
             g_scratch_ptr[device] = static_cast<unsigned char*>(sp);
         }
         scratch_dev = g_scratch_ptr[device];
@@ -717,6 +733,7 @@ int rt_init(int device, rt_ctx** out)
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamDefault)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_null, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_slab, hipEventDisableTiming)) != hipSuccess ||
         (e = hipMalloc((void**)&c->d_stats, sizeof(unsigned long long) * ST_TOTAL)) != hipSuccess ||
         (e = hipMalloc((void**)&c->d_counters, sizeof(uint32_t) * C_TOTAL)) != hipSuccess ||
         (e = hipEventCreate(&c->ev_begin)) != hipSuccess || (e = hipEventCreate(&c->ev_end)) != hipSuccess) {
@@ -738,6 +755,7 @@ int rt_shutdown(rt_ctx* c)
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->ev_null) (void)hipEventDestroy(c->ev_null);
+    if (c->ev_slab) (void)hipEventDestroy(c->ev_slab);
     (void)hipFree(c->batch_mem); (void)hipFree(c->d_stats); (void)hipFree(c->d_counters);
     (void)hipFree(c->d_rgb); (void)hipFree(c->d_prim); (void)hipFree(c->d_t);
     (void)hipFree(c->d_slab); (void)hipFree(c->d_gather);
@@ -974,7 +992,7 @@ int rt_owned_tiles(const rt_params* p, int rank, int world, uint32_t* out)
 // [fixed_mem, fixed_mem + fixed_bytes) and nothing is allocated, freed, created or read back.
 static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, float* d_rgb, uint32_t* d_prim,
                          float* d_t, rt_stats* stats, hipStream_t stream, bool slab, bool wait,
-                         unsigned char* fixed_mem = nullptr, size_t fixed_bytes = 0)
+                         unsigned char* fixed_mem = nullptr, size_t fixed_bytes = 0, bool capturing = false)
 {
     rt_ctx* ctx = s->ctx;
     const DScene& S = s->dev;
@@ -994,12 +1012,13 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
     const uint64_t per_tile = (uint64_t)RT_TILE * RT_TILE * (uint64_t)A.spp;
     const uint32_t nl = S.num_lights ? S.num_lights : 1;
     const uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
-    // Paths per batch.  Default: as many as the 29-bit ray ids of the BVH queue items allow (P * n^2 < 2^29), at
-    // most 32 Mi, in equal batches (4K, 16 spp, 4x4 AO: 4 batches of 510 tiles, ~52 GB of the 288 GB) — every
-    // launch of a persistent kernel ends in a drain tail, so fewer, larger batches are faster (8 -> 4: +1 %).
-    uint64_t want = p->batch_paths ? p->batch_paths : (32u << 20);
+    // Paths per batch.  Default: as many as the 31-bit ray ids of the BVH queue items allow (P * n^2 < 2^31), at
+    // most 64 Mi, in equal batches (4K, 16 spp, 4x4 AO: 2 batches of 1020 tiles, ~104 GB of the 288 GB) — every
+    // launch of a persistent kernel ends in a drain tail, so fewer, larger batches are faster (8 -> 4: +1 %; round 3,
+    // 4 -> 2 with the ids widened from 29 to 31 bits).
+    uint64_t want = p->batch_paths ? p->batch_paths : (64u << 20);
     if (!p->batch_paths) {
-        want = std::min<uint64_t>(want, ((1ull << 29) - 1) / (n2 ? n2 : 1));
+        want = std::min<uint64_t>(want, ((1ull << 31) - 1) / (n2 ? n2 : 1));
         want = std::min<uint64_t>(want, 0xFFFFFFFFull / nl);
     }
     uint32_t tiles_per_batch = (uint32_t)std::min<uint64_t>(want / per_tile, 0x7FFFFFFFull);
@@ -1019,7 +1038,7 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
             }
             size_t need = ~(size_t)0;
             const uint64_t paths = (uint64_t)tiles_per_batch * per_tile;
-            if (paths <= 0x7FFFFFFFull && paths * nl <= 0xFFFFFFFFull && paths * (n2 ? n2 : 1) < (1ull << 29)) {
+            if (paths <= 0x7FFFFFFFull && paths * nl <= 0xFFFFFFFFull && paths * (n2 ? n2 : 1) < (1ull << 31)) {
                 P = (uint32_t)paths;
                 need = carve_batch(B, nullptr, P, levels_alloc, nl, n2);
             }
@@ -1045,7 +1064,7 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
         }
         if ((uint64_t)tiles_per_batch * per_tile > 0x7FFFFFFFull) { ctx->error = "rt_render: one tile x num_samples exceeds 2^31 paths"; return RT_ERR_UNSUPPORTED; }
         P = (uint32_t)(tiles_per_batch * per_tile);
-        if ((uint64_t)P * nl > 0xFFFFFFFFull || (uint64_t)P * (n2 ? n2 : 1) >= (1ull << 29)) {   // 29-bit ray ids in the BVH queue items
+        if ((uint64_t)P * nl > 0xFFFFFFFFull || (uint64_t)P * (n2 ? n2 : 1) >= (1ull << 31)) {   // 31-bit ray ids in the BVH queue items
             ctx->error = "rt_render: batch too large for 32-bit queue entries; lower batch_paths"; return RT_ERR_UNSUPPORTED; }
         const size_t need = carve_batch(B, nullptr, P, levels_alloc, nl, n2);
         if (need <= ctx->batch_bytes) break;
@@ -1070,9 +1089,9 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
     // the refilling gate walk pays off when a ray tests many gate nodes (config 5: ~100 of 7500; config 3: 2 of 8)
     be.walk_refill = ((S.num_gates > RT_LDS_GATES && !(S.debug & 32u)) || (S.debug & 16u)) && n2 > 0;
     be.ovf_bits_bytes = 4ull * (B.ovf_cap / 32u + 1u);
-    if ((S.debug & 4u) || (uint64_t)P * nl >= (1ull << 29)) be.S.shadow_defer = 0;   // experiment switch / the queue item's 29-bit destination
-    {   // the batch buffers, counters and statistics are the context's: wait for their previous user (any stream)
-        const int rc = order_after_previous_work(ctx, stream);
+    if ((S.debug & 4u) || (uint64_t)P * nl >= (1ull << 31)) be.S.shadow_defer = 0;   // experiment switch / the queue item's 31-bit destination
+    if (!capturing) {   // the batch buffers, counters and statistics are the context's: wait for their previous user (any stream)
+        const int rc = order_after_previous_work(ctx, stream);   // (a capturing stream may not wait on an event recorded outside the capture)
         if (rc) return rc;
     }
     HIPCHECK(ctx, hipMemsetAsync(B.stats, 0, sizeof(unsigned long long) * ST_TOTAL, stream));   // the array keeps the last call's contents
@@ -1083,7 +1102,7 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
         batches = (owned + tiles_per_batch - 1) / tiles_per_batch;
     }
     if (!fixed_mem) HIPCHECK(ctx, hipEventRecord(ctx->ev_end, stream));
-    {
+    if (!capturing) {   // (an event recorded inside a capture is no event later eager work could wait on)
         const int rc = mark_done(ctx, stream);
         if (rc) return rc;
     }
@@ -1104,6 +1123,7 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
         }
         stats->rays_primary = prim * (uint64_t)A.spp;
         stats->rays_shadow = h[ST_SHADOW]; stats->rays_ao = h[ST_AO]; stats->rays_bounce = h[ST_BOUNCE];
+        stats->rays_skipped = h[ST_SKIPPED];
         if (getenv("RT_BVH_DIAG") && h[ST_DIAG + 0] + h[ST_DIAG + 2] > 0)
             std::fprintf(stderr, "[k_bvh<AO>] node steps %llu (%.1f lanes each), triangle steps %llu (%.1f lanes each), votes %llu (%.1f active lanes), refills %llu (%.1f rays each)\n",
                          h[ST_DIAG], (double)h[ST_DIAG + 1] / std::max(1ull, h[ST_DIAG]), h[ST_DIAG + 2], (double)h[ST_DIAG + 3] / std::max(1ull, h[ST_DIAG + 2]),
@@ -1154,8 +1174,26 @@ int rt_render_device_noalloc(rt_scene* s, const rt_camera* cam, const rt_params*
     if (!ctx->scratch_ptr) { ctx->error = "rt_render_device_noalloc: scratch address was not resolved at rt_init"; return RT_ERR_STATE; }
     HIPCHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    // Under stream capture the call only adds kernel and memset nodes to the caller's graph: no event is waited on or
+    // recorded (a capturing stream may not wait on events recorded outside the capture, and an event recorded inside
+    // it orders nothing afterwards); the stream's own order serialises the call's work, and the caller orders graph
+    // replays against other users of this GPU's scratch.
+    bool capturing = false;
+    if (stream) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        HIPCHECK(ctx, hipStreamIsCapturing(st, &cs));
+        capturing = cs != hipStreamCaptureStatusNone;
+    }
     if (!stream) { rc = order_after_null_stream(ctx); if (rc) return rc; }
-    rc = render_locked(s, cam, p, d_rgb, d_primid, d_t, nullptr, st, p->tile_world > 1, false, ctx->scratch_ptr, (size_t)RT_NOALLOC_SCRATCH_BYTES);
+    if (!capturing) {   // the previous user of this GPU's scratch, whatever context it came through
+        std::lock_guard<std::mutex> sl(g_scratch_mu);
+        if (g_scratch_ev_recorded[ctx->device]) HIPCHECK(ctx, hipStreamWaitEvent(st, g_scratch_ev[ctx->device], 0));
+    }
+    rc = render_locked(s, cam, p, d_rgb, d_primid, d_t, nullptr, st, p->tile_world > 1, false, ctx->scratch_ptr, (size_t)RT_NOALLOC_SCRATCH_BYTES, capturing);
+    if (!capturing) {   // also after a failed call: whatever it queued before failing still uses the array
+        std::lock_guard<std::mutex> sl(g_scratch_mu);
+        if (hipEventRecord(g_scratch_ev[ctx->device], st) == hipSuccess) g_scratch_ev_recorded[ctx->device] = true;
+    }
     if (rc) return rc;
     if (!stream) HIPCHECK(ctx, hipStreamSynchronize(st));
     return RT_OK;
@@ -1278,8 +1316,25 @@ int rt_render_multi(rt_scene* const* scenes, int num_scenes, const rt_camera* ca
         const size_t bytes = (size_t)owned * RT_TILE * RT_TILE * 3 * sizeof(float);
         float* dst = ctx0->d_gather + slab_floats * (size_t)i;
         if (ctx->device == ctx0->device) HIPCHECK(ctx, hipMemcpyAsync(dst, ctx->d_slab, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-        else HIPCHECK(ctx, hipMemcpyPeerAsync(dst, ctx0->device, ctx->d_slab, ctx->device, bytes, ctx->stream));   // one xGMI link per peer, all ranks at once
-        HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+        else {
+            // direct access to the gathering GPU's memory, enabled once per pair: without it the peer copy is staged
+            // through the host instead of crossing this GPU's own xGMI link to GPU 0
+            if (std::find(ctx->peers_enabled.begin(), ctx->peers_enabled.end(), ctx0->device) == ctx->peers_enabled.end()) {
+                int can = 0;
+                HIPCHECK(ctx, hipDeviceCanAccessPeer(&can, ctx->device, ctx0->device));
+                if (can) {
+                    const hipError_t pe = hipDeviceEnablePeerAccess(ctx0->device, 0);
+                    if (pe == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                    else if (pe != hipSuccess) { ctx->error = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe); return RT_ERR_HIP; }
+                } else {
+                    std::fprintf(stderr, "rt_render_multi: GPU %d cannot access GPU %d directly (hipDeviceCanAccessPeer = 0): "
+                                         "its tile slab is staged through the host\n", ctx->device, ctx0->device);
+                }
+                ctx->peers_enabled.push_back(ctx0->device);
+            }
+            HIPCHECK(ctx, hipMemcpyPeerAsync(dst, ctx0->device, ctx->d_slab, ctx->device, bytes, ctx->stream));   // one xGMI link per peer, all ranks at once
+        }
+        HIPCHECK(ctx, hipEventRecord(ctx->ev_slab, ctx->stream));   // the gathering GPU unpacks this slab as soon as it has landed
         return RT_OK;
     };
     {
@@ -1303,6 +1358,8 @@ int rt_render_multi(rt_scene* const* scenes, int num_scenes, const rt_camera* ca
         uint32_t owned = 0;
         rt_owned_tiles(&base, i, num_scenes, &owned);
         if (owned == 0) continue;
+        // per-rank order: the unpack of rank i waits (on the device) for rank i's copy only, not for every rank
+        if (i != 0) HIPCHECK(ctx0, hipStreamWaitEvent(ctx0->stream, scenes[i]->ctx->ev_slab, 0));
         hipLaunchKernelGGL(k_unpack, dim3(grid_for((uint64_t)owned * RT_TILE * RT_TILE)), dim3(RT_BLOCK), 0, ctx0->stream,
                            ctx0->d_gather + slab_floats * (size_t)i, ctx0->d_rgb, p->width, p->x0, p->y0, p->x1, p->y1, tx, ty, i, num_scenes, owned);
     }

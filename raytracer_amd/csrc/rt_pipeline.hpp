@@ -28,7 +28,8 @@ enum { C_QUEUE = 0, C_AO = 64, C_SH = 128, C_BQ = 192, C_BQA = 256, C_BQ_NEXT = 
        C_AOW = 704 /* k_ao_walk: next unclaimed AO item */, C_TOTAL = 768 };   // per-batch u32 counters, one per depth
 enum { ST_SHADOW = 0, ST_AO = 1, ST_BOUNCE = 2, ST_NODES = 3, ST_TRIS = 6, ST_GATES = 9, ST_BVHRAYS = 12,
        ST_DIAG = 15 /* k_bvh<AO> lane-packing diagnostics of the counting variant: node steps, lanes in them, triangle steps, lanes in them, votes, active lanes at votes, refills, lanes refilled */,
-       ST_TOTAL = 23 }; // u64
+       ST_SKIPPED = 23 /* closest-hit queries the reference traces and this path proves unnecessary (prep_item) */,
+       ST_TOTAL = 24 }; // u64
 #define RT_MAX_LEVELS 62
 
 struct Batch {
@@ -229,6 +230,19 @@ RT_FN void close_cursor(const QCursor& qc, uint32_t* holes, uint32_t hole_value,
 #endif
 }
 
+// Queue item word b.w: the ray's destination index (31 bits) | bit 31 when the item carries more than one mesh root.
+// The roots of an item lie in bq_roots[k * bq_cap + slot], k = 0 .. sp-1; an item with 1 < sp < RT_DEFER_ROOTS roots
+// ends its list with REF_NONE (round 3: the count used to ride in three bits of b.w, which left 29 bits for the
+// destination and forced a 4K / 16 spp / 4x4 AO frame into four batches).
+#define RT_BQ_MULTI 0x80000000u
+#define RT_BQ_DST_MASK 0x7FFFFFFFu
+RT_FN uint32_t bq_word(uint32_t dst, uint32_t sp) { return dst | (sp > 1u ? RT_BQ_MULTI : 0u); }
+RT_FN void bq_store_roots(const Batch& B, uint32_t slot, Stack st, uint32_t sp)
+{
+    for (uint32_t k = 0; k < sp; ++k) B.bq_roots[(size_t)k * B.bq_cap + slot] = st.p[k * st.stride];
+    if (sp > 1u && sp < RT_DEFER_ROOTS) B.bq_roots[(size_t)sp * B.bq_cap + slot] = REF_NONE;
+}
+
 // One closest-hit query (the scene loop of raytrace(), Reflective::rho, Transparency::rho).  Like ao_item the hot
 // kernel traverses nothing: planes / spheres / free triangles are tested in place, the roots of the Meshes whose
 // gates pass ride in ONE queue item for k_bvh (a closest-hit record cannot be combined from several items the way
@@ -259,10 +273,10 @@ RT_FN void trace_item(const DScene& S, const RenderArgs& A, const Batch& B, int 
     const uint32_t slot = chunk_append<RT_QCHUNK>(&B.counters[C_BQ + depth], want, qc, B.bq_roots, (uint32_t)REF_NONE, B.cq_cap);
     if (want && slot < B.cq_cap) {
         const q4 a = {o.x, o.y, o.z, h.t};
-        const q4 b = {d.x, d.y, d.z, u2f(p | ((sp - 1u) << 29))};   // p < 2^29 (checked where the batch is sized); 1 <= sp <= RT_DEFER_ROOTS
+        const q4 b = {d.x, d.y, d.z, u2f(bq_word(p, sp))};   // p < 2^31 (checked where the batch is sized); 1 <= sp <= RT_DEFER_ROOTS
         const q4 c = {u2f(h.prim), u2f(h.rank), h.u, h.v};
         B.bq_a[slot] = a; B.bq_b[slot] = b; B.bq_c[slot] = c;
-        for (uint32_t k = 0; k < sp; ++k) B.bq_roots[(size_t)k * B.bq_cap + slot] = st.p[k * st.stride];
+        bq_store_roots(B, slot, st, sp);
         return;   // k_bvh writes hit[p]
     }
     if (want) overflow = true;   // queue full
@@ -298,11 +312,13 @@ RT_FN void bvh_item(const DScene& S, const Batch& B, uint32_t idx, Stack st, Cou
     Hit best; best.t = a.w; best.prim = H_MISS; best.rank = 0; best.u = 0; best.v = 0;
     if (MODE == BVH_CLOSEST) { q4 c = B.bq_c[idx]; best.prim = f2u(c.x); best.rank = f2u(c.y); best.u = c.z; best.v = c.w; }
     RayCull4 rc = make_cull4(S, o, d);
-    const uint32_t nroots = (f2u(b.w) >> 29) + 1u, dst = f2u(b.w) & 0x1FFFFFFFu;
+    const uint32_t dst = f2u(b.w) & RT_BQ_DST_MASK;
+    const uint32_t maxroots = (f2u(b.w) & RT_BQ_MULTI) ? (uint32_t)RT_DEFER_ROOTS : 1u;
     if (B.bq_roots[idx] == REF_NONE) return;   // hole
-    for (uint32_t k = 0; k < nroots; ++k) {
+    for (uint32_t k = 0; k < maxroots; ++k) {
         uint32_t sp = 1;
         st.p[0] = B.bq_roots[(size_t)k * B.bq_cap + idx];
+        if (st.p[0] == REF_NONE) break;   // end of a multi-root list
         if (MODE == BVH_SHADOW) {
             if (bvh_drain<STATS, true>(S, o, d, rc, best, st, sp, cnt)) { B.sh_res[dst] = 0.0f; return; }
         } else bvh_drain<STATS, false>(S, o, d, rc, best, st, sp, cnt);
@@ -313,7 +329,9 @@ RT_FN void bvh_item(const DScene& S, const Batch& B, uint32_t idx, Stack st, Cou
 
 // Returns true when the path's material consumes shadow rays (Specular / Textured); P and N are then
 // the hit point and shading normal.  The AO "queue" is positional: slot = idx, no append.
-RT_FN bool prep_body(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, uint32_t& p_out, f3& P_out, f3& N_out)
+// `skipped` counts the queries of the reference that are not traced here: Ambient::L's n*n rays of a surface whose
+// ka is 0 (the reference traces them and multiplies the factor away, main.cpp:1497 with main.cpp:1714's ka = 0).
+RT_FN bool prep_body(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, uint32_t& p_out, f3& P_out, f3& N_out, uint32_t& skipped)
 {
     { q4 none = {0.0f, 0.0f, 0.0f, u2f(0xFFFFFFFFu)}; B.ao_w[idx] = none; }
     uint32_t p = item_path(A, B, depth, idx);
@@ -352,6 +370,7 @@ RT_FN bool prep_body(const DScene& S, const RenderArgs& A, const Batch& B, int d
         uint32_t a = ps & 0xFFu;
         ps = ((a + 1u) & 0xFFu) | (a << 8);
         B.pstate[p] = ps;
+        if (M.ka == 0.0f) skipped += (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
         if (M.ka != 0.0f) {   // ka == 0 multiplies the (finite) occlusion factor away: no rays needed
             slot = idx;
             f3 ao, au, aw;
@@ -392,17 +411,21 @@ RT_FN bool prep_body(const DScene& S, const RenderArgs& A, const Batch& B, int d
 
 // `valid` = idx addresses a path; all 64 lanes of a wave call this together (GPU): the shadow-ray
 // appends go through the wave's chunked cursor.
-RT_FN void prep_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, bool valid, QCursor& qsh)
+// `skipped` += the reference's queries that this path does not trace (rt_stats.rays_skipped): the shadow ray of a
+// light the surface faces away from (the reference calls shadowed() before it tests n.wi, main.cpp:1227, 1281) and
+// the AO rays of a surface with ka = 0 (prep_body).
+RT_FN void prep_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, bool valid, QCursor& qsh, uint32_t& skipped)
 {
     uint32_t p = 0;
     f3 P = F3(0, 0, 0), N = F3(0, 0, 1);
-    const bool lit = valid && prep_body(S, A, B, depth, idx, p, P, N);
+    const bool lit = valid && prep_body(S, A, B, depth, idx, p, P, N, skipped);
     // the shadow ray is only consumed when n.wi > 0 (main.cpp:1227-1237, 1281-1293)
     for (uint32_t l = 0; l < S.num_lights; ++l) {
         bool want = false;
         if (lit) {
             f3 wi = normalize(light_direction(S.lights[l], P));
             want = dot(N, wi) > 0.0f;
+            if (!want) skipped++;
         }
         const uint32_t e = chunk_append<RT_SHCHUNK>(&B.counters[C_SH + depth], want, qsh, B.sh_queue, 0xFFFFFFFFu, B.sh_cap);
         if (want && e < B.sh_cap) B.sh_queue[e] = p * S.num_lights + l;   // sh_cap covers the worst case (carve_batch)
@@ -459,9 +482,9 @@ RT_FN void shadow_defer_item(const DScene& S, const RenderArgs& A, const Batch& 
     if (want) {
         if (slot < B.bq_cap) {
             const q4 a = {src.x, src.y, src.z, dist};
-            const q4 b = {dir.x, dir.y, dir.z, u2f(e | ((sp - 1u) << 29))};   // e < 2^29 (checked where shadow_defer is decided)
+            const q4 b = {dir.x, dir.y, dir.z, u2f(bq_word(e, sp))};   // e < 2^31 (checked where shadow_defer is decided)
             B.bq_a[slot] = a; B.bq_b[slot] = b;
-            for (uint32_t k = 0; k < sp; ++k) B.bq_roots[(size_t)k * B.bq_cap + slot] = st.p[k * st.stride];
+            bq_store_roots(B, slot, st, sp);
         } else overflow = true;   // queue full
     }
 }
@@ -534,9 +557,9 @@ RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int dep
             if (want) {
                 if (item < B.bq_cap) {
                     const q4 a = {o.x, o.y, o.z, h.t};   // an upper bound of the ray's distance: the minimum is taken at the destination
-                    const q4 b = {dir.x, dir.y, dir.z, u2f(dst | ((sp - 1u) << 29))};   // dst < 2^29 (checked where the batch is sized); 1 <= sp <= RT_DEFER_ROOTS
+                    const q4 b = {dir.x, dir.y, dir.z, u2f(bq_word(dst, sp))};   // dst < 2^31 (checked where the batch is sized); 1 <= sp <= RT_DEFER_ROOTS
                     B.bq_a[item] = a; B.bq_b[item] = b;
-                    for (uint32_t r = 0; r < sp; ++r) B.bq_roots[(size_t)r * B.bq_cap + item] = st.p[r * st.stride];
+                    bq_store_roots(B, item, st, sp);
                 } else overflow = true;
                 sp = 0;
             }

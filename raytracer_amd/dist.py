@@ -73,3 +73,33 @@ def gather_frame(slab, params, rank, world, unpack, group=None, gather_list=None
             unpack(src, gather_list[src])
         return True
     return False
+
+
+class PendingGather:
+    """A gather in flight (gather_frame_start): finish() waits for it and scatters the slabs on rank 0."""
+    def __init__(self, work, gather_list, rank, world, unpack, keep):
+        self.work, self.gather_list, self.rank, self.world, self.unpack, self.keep = work, gather_list, rank, world, unpack, keep
+
+    def finish(self):
+        if self.work is not None:
+            self.work.wait()   # device tensors: the current stream waits for the collective, the host does not
+        if self.rank == 0:
+            for src in range(self.world):
+                self.unpack(src, self.gather_list[src])
+        self.keep = None
+        return self.rank == 0
+
+
+def gather_frame_start(slab, params, rank, world, unpack, group=None, gather_list=None, force_collective=False):
+    """The same exchange as gather_frame, split in two so that a caller with two slabs can render frame k+1 while
+    frame k's slabs travel: start the gather (async_op), return a PendingGather; call finish() on it later — after
+    queueing the next render.  `slab` and `gather_list` must stay untouched until finish().  world == 1 runs no
+    collective unless force_collective (how the RCCL code path is exercised on a one-GPU box)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1 and not force_collective:
+        return PendingGather(None, [slab], 0, 1, unpack, slab)
+    if gather_list is None and rank == 0:
+        gather_list = [torch.empty_like(slab) for _ in range(world)]
+    work = dist.gather(slab, gather_list if rank == 0 else None, dst=0, group=group, async_op=True)
+    return PendingGather(work, gather_list, rank, world, unpack, slab)

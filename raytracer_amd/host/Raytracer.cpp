@@ -180,7 +180,18 @@ void render_rect(int y0, int y1, int x0, int x1, rt_camera cam, std::shared_ptr<
     } else {
         std::vector<rt_stats> per(g.ctx.size());
         if (rt_render_multi(g.scene.data(), (int)g.scene.size(), &cam, &p, image, stats ? per.data() : nullptr) != RT_OK) fail("rt_render_multi", g.ctx[0]);
-        if (stats) *stats = per[0];   // rank 0's record (ray counts are per rank)
+        if (stats) {   // the frame's record: counters summed over the ranks, times = the slowest rank's
+            *stats = per[0];
+            for (size_t r = 1; r < per.size(); ++r) {
+                const rt_stats& q = per[r];
+                stats->rays_primary += q.rays_primary; stats->rays_shadow += q.rays_shadow; stats->rays_ao += q.rays_ao;
+                stats->rays_bounce += q.rays_bounce; stats->rays_skipped += q.rays_skipped;
+                for (int k = 0; k < 3; ++k) { stats->nodes[k] += q.nodes[k]; stats->tris[k] += q.tris[k]; stats->gates[k] += q.gates[k]; stats->bvh_rays[k] += q.bvh_rays[k]; }
+                if (q.ms_total > stats->ms_total) stats->ms_total = q.ms_total;
+                for (int k = 0; k < RT_K_COUNT; ++k) { if (q.ms_kernel[k] > stats->ms_kernel[k]) stats->ms_kernel[k] = q.ms_kernel[k]; stats->launches[k] += q.launches[k]; }
+                stats->batches += q.batches;
+            }
+        }
     }
 }
 

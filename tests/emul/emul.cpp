@@ -44,7 +44,12 @@ struct LoopBackend {
         Stack st{stack.data(), 1};
         for (uint32_t i = 0, n = std::min(B.counters[C_BQA + d], B.bq_cap); i < n; ++i) bvh_item<BVH_AO, true>(S, B, i, st, cnt[2]);
     }
-    void prep(const RenderArgs& A, int d, uint32_t fixed) { QCursor q{0, 0}; for (uint32_t i = 0, n = count(d, fixed); i < n; ++i) prep_item(S, A, B, d, i, true, q); }
+    void prep(const RenderArgs& A, int d, uint32_t fixed) {
+        QCursor q{0, 0};
+        uint32_t skipped = 0;
+        for (uint32_t i = 0, n = count(d, fixed); i < n; ++i) prep_item(S, A, B, d, i, true, q, skipped);
+        B.stats[ST_SKIPPED] += skipped;
+    }
     void shadow(const RenderArgs& A, int d) {
         Stack st{stack.data(), 1};
         const uint32_t n = B.counters[C_SH + d];
@@ -92,7 +97,7 @@ extern "C" {
 static std::string g_err;
 const char* emul_last_error() { return g_err.c_str(); }
 
-// out_counts: {primary, shadow, ao, bounce, nodes[3], tris[3], gates[3]}
+// out_counts: {primary, shadow, ao, bounce, nodes[3], tris[3], gates[3], skipped}
 int emul_render(const rt_scene_desc* d, const rt_camera* cam, const rt_params* p,
                 float* rgb, uint32_t* primid, float* t, unsigned long long* out_counts)
 {
@@ -164,6 +169,7 @@ int emul_render(const rt_scene_desc* d, const rt_camera* cam, const rt_params* p
         out_counts[0] = (unsigned long long)(p->x1 - p->x0) * (p->y1 - p->y0) * A.spp;
         out_counts[1] = stats[ST_SHADOW]; out_counts[2] = stats[ST_AO]; out_counts[3] = stats[ST_BOUNCE];
         for (int k = 0; k < 3; ++k) { out_counts[4 + k] = be.cnt[k].nodes; out_counts[7 + k] = be.cnt[k].tris; out_counts[10 + k] = be.cnt[k].gates; }
+        out_counts[13] = stats[ST_SKIPPED];
     }
     return 0;
 }

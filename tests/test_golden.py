@@ -38,6 +38,8 @@ def test_device_code_on_host_matches_reference_fixture(emul, name, world, params
     assert np.array_equal(t[same].view(np.uint32), g["t"][same].view(np.uint32))
     assert util.lsb_diff(rgb, g["rgb"]).max() <= 1
     assert (rgb.view(np.uint32) == g["rgb"].view(np.uint32)).mean() >= 0.95
+    # the metric's numerator: queries traced + queries proven unnecessary == the reference's own count (SURVEY 8d unit)
+    assert int(cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[13]) == int(g["rays"])
 
 
 def test_known_answer_vectors(port):

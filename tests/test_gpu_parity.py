@@ -36,6 +36,7 @@ def test_matches_oracle(gpu, port, name, world, params):
     print(f"{name}: ids {same.mean():.6f}  rgb bit-exact {exact:.4f}  max|d| {np.abs(rgb - want.rgb).max():.3g}  rays {st.rays}")
     assert exact >= 0.95
     assert st.rays_primary == params.width * params.height * params.num_samples
+    assert st.rays + st.rays_skipped == want.rays   # the oracle counts the reference's queries
 
 
 def test_deterministic_and_idempotent(gpu):
@@ -153,6 +154,10 @@ def test_matches_reference_fixture(gpu, name, world, params, builder):
     assert np.array_equal(t[same].view(np.uint32), g["t"][same].view(np.uint32))
     assert util.lsb_diff(rgb, g["rgb"]).max() <= 1
     assert util.psnr(rgb, g["rgb"]) >= 45.0
+    # the metric's numerator (Mrays/s): what this path traced + what it proved unnecessary is the reference's own
+    # count of closest-hit queries for the frame (SURVEY 8d's unit, main.cpp:1645-1648), exactly
+    assert st.rays + st.rays_skipped == int(g["rays"]), (st.rays, st.rays_skipped, int(g["rays"]))
+    assert st.rays_reference_unit == int(g["rays"])
 
 
 @pytest.fixture(scope="module")

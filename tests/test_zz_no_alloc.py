@@ -87,3 +87,64 @@ def test_noalloc_rejects_what_does_not_fit(gpu):
     p.flags = 0
     gpu.render_device_noalloc(world.camera, p, out.data_ptr())   # and the context still works afterwards
     assert float(out.max()) > 0.0
+
+
+def test_noalloc_under_graph_capture(gpu):
+    """The use case the header names: the call captured into a HIP graph (kernel and memset nodes only: no event is
+    waited on or recorded while the stream captures), replayed twice, against rt_render_device."""
+    import torch
+    name, world, params = util.small_scenes()[2]
+    gpu.upload(world)
+    dev = torch.device("cuda", 0)
+    H, W = params.height, params.width
+    want = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    gpu.render_device(world.camera, params, want.data_ptr(), None, None, None, torch.cuda.current_stream().cuda_stream)
+    out = torch.full((H, W, 3), -1.0, dtype=torch.float32, device=dev)
+    gpu.render_device_noalloc(world.camera, params, out.data_ptr(), None, None, torch.cuda.current_stream().cuda_stream)   # warm-up outside the capture
+    torch.cuda.synchronize()
+    assert util.bits_equal(out.cpu().numpy(), want.cpu().numpy())
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        gpu.render_device_noalloc(world.camera, params, out.data_ptr(), None, None, torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):
+        out.fill_(-1.0)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert util.bits_equal(out.cpu().numpy(), want.cpu().numpy())
+    # and the context still renders eagerly afterwards, on another stream
+    out.fill_(-1.0)
+    gpu.render_device_noalloc(world.camera, params, out.data_ptr(), None, None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert util.bits_equal(out.cpu().numpy(), want.cpu().numpy())
+
+
+def test_noalloc_calls_through_two_contexts_of_one_gpu_serialise(gpu):
+    """Every context of a GPU shares that GPU's scratch array: calls through different contexts on different streams
+    are ordered by the library (one 'last user' event per device), so both frames come out right."""
+    import torch
+    from raytracer_amd.render import Renderer
+    name, world, params = util.small_scenes()[2]
+    flat = world.flatten()
+    gpu.upload(flat)
+    dev = torch.device("cuda", 0)
+    H, W = params.height, params.width
+    want = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    gpu.render_device(world.camera, params, want.data_ptr(), None, None, None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    other = Renderer(0)
+    try:
+        other.upload(flat)
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        a = torch.full((H, W, 3), -1.0, dtype=torch.float32, device=dev)
+        b = torch.full((H, W, 3), -1.0, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        for _ in range(3):
+            gpu.render_device_noalloc(world.camera, params, a.data_ptr(), None, None, s1.cuda_stream)
+            other.render_device_noalloc(world.camera, params, b.data_ptr(), None, None, s2.cuda_stream)
+        torch.cuda.synchronize()
+        assert util.bits_equal(a.cpu().numpy(), want.cpu().numpy())
+        assert util.bits_equal(b.cpu().numpy(), want.cpu().numpy())
+    finally:
+        other.close()

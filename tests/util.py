@@ -24,7 +24,7 @@ class Emul:
         rgb = np.zeros((H, W, 3), np.float32)
         pid = np.full((H, W), capi.RT_MISS, np.uint32)
         t = np.zeros((H, W), np.float32)
-        cnt = np.zeros(13, np.uint64)
+        cnt = np.zeros(14, np.uint64)
         cam = camera.to_c()
         rc = self.lib.emul_render(C.byref(flat.desc), C.byref(cam), C.byref(params), rgb.ctypes.data,
                                   pid.ctypes.data, t.ctypes.data, cnt.ctypes.data)
