@@ -40,8 +40,16 @@ using namespace rt;
 #endif
 
 // MODE: BVH_CLOSEST (hit records), BVH_AO (distances only), BVH_SHADOW (any hit before the light ends the ray).
+// Register budget for 6 waves per SIMD (80 VGPRs; the timed variants fit without scratch, the counting variants spill
+// a little).  This kernel's time follows the waves that fit: with LDS padding that leaves 5 / 4 / 3 / 2 waves per SIMD
+// k_bvh<AO> takes 103 / 117 / 143 / 199 ms on config 3 (T ~ 32 + 334 / waves: two thirds of it is memory latency that
+// only more resident waves hide), see DESIGN.md 4.
+#ifndef RT_BVH_WAVES
+#define RT_BVH_WAVES 6
+#endif
+#define RT_BVH_ATTR __attribute__((amdgpu_waves_per_eu(RT_BVH_WAVES, RT_BVH_WAVES)))
 template <int MODE, bool STATS>
-__global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int counter, int next_counter)
+__global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR k_bvh(DScene S, Batch B, int counter, int next_counter)
 {
     constexpr bool AO = MODE != BVH_CLOSEST;   // the queue layout of the distance-only queries: no bq_c, bq_cap slots
     // Per-lane stack of {reference, entry distance of its box}, [entry][lane] (conflict-free).  The distance lets
@@ -49,9 +57,15 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
     // fetching the node (18 % of the node fetches of an AO ray otherwise).
     __shared__ uint2 s_stack[RT_LDS_STACK * RT_BVH_BLOCK];
     __shared__ uint32_t s_pend[RT_PEND * RT_BVH_BLOCK];
+#ifdef RT_BVH_LDS_PAD   // experiment: fewer resident waves (round 3: is the kernel bound by issue or by latency? see DESIGN.md 4)
+    __shared__ uint32_t s_pad[RT_BVH_LDS_PAD / 4];
+    if (counter == 0x7FFFFFFF) s_pad[threadIdx.x] = 1u;
+#endif
     // volatile: keeps the (rare) global spill accesses from being merged with the LDS ones into
     // generic-pointer (flat) instructions, which wait on both memory counters
-    volatile uint2* const spill = (volatile uint2*)B.bq_spill + (size_t)blockIdx.x * RT_BVH_BLOCK + threadIdx.x;
+    // (formed from the kernel argument + a 32-bit lane offset at each use: a 64-bit pointer held per lane would cost two
+    // registers for the life of the kernel, and this kernel's time falls with every wave that fits — DESIGN.md 4)
+    #define spill ((volatile uint2*)B.bq_spill + ((size_t)blockIdx.x * RT_BVH_BLOCK + threadIdx.x))
     const size_t spill_stride = (size_t)RT_BVH_GRID * RT_BVH_BLOCK;
     auto push = [&](uint32_t& sp_, uint32_t x, float tn) {
         if (sp_ < RT_LDS_STACK) s_stack[sp_ * RT_BVH_BLOCK + threadIdx.x] = make_uint2(x, f2u(tn));
@@ -77,14 +91,15 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
     f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
     RayCull4 rc = {};
     Hit best = {};
-    uint32_t sp = 0, cur = REF_NONE, dst = 0, npend = 0, tri_next = 0, tri_left = 0;
+    uint32_t sp = 0, cur = REF_NONE, dst = 0, npend = 0;
+    uint32_t tri = 0;   // triangles of the leaf being tested: next slot (bits 0..27) | triangles left (bits 28..31)
     bool active = false, exhausted = false;
     uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform
     uint32_t nrays = 0;
     uint32_t dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // STATS: wave-uniform diagnostics (see ST_DIAG)
     for (;;) {
         // ---- retire finished rays -------------------------------------------------------------
-        if (active && cur == REF_NONE && npend == 0 && tri_left == 0) {
+        if (active && cur == REF_NONE && npend == 0 && (tri >> 28) == 0u) {
             if (MODE == BVH_AO) key_min(&B.ao_key[dst], t_key(best.t));   // the ray's other items and k_ao's own hit meet here
             else if (MODE == BVH_SHADOW) { if (best.prim != H_MISS) B.sh_res[dst] = 0.0f; }   // k_shadow_defer stored what holds otherwise
             else { const q4 r = {best.t, u2f(best.prim), best.u, best.v}; B.hit[dst] = r; }
@@ -121,7 +136,7 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
                     best.t = a.w; best.prim = H_MISS; best.rank = 0; best.u = 0; best.v = 0;
                     if (!AO) { const q4 c = B.bq_c[idx]; best.prim = f2u(c.x); best.rank = f2u(c.y); best.u = c.z; best.v = c.w; }
                     rc = make_cull4(S, o, d);
-                    sp = 0; npend = 0; tri_left = 0;
+                    sp = 0; npend = 0; tri = 0;
                     if (root0 != REF_NONE) {
                         push(sp, root0, -INFINITY);
                         if (multi)   // rare: one Mesh is the rule; a list shorter than RT_DEFER_ROOTS ends with REF_NONE
@@ -137,7 +152,7 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
         }
         // ---- vote for the kind of step ------------------------------------------------------------
         const bool can_node = active && cur != REF_NONE && (!(cur & REF_LEAF) || npend < RT_PEND);
-        const bool can_tri = active && (tri_left > 0 || npend > 0);
+        const bool can_tri = active && ((tri >> 28) != 0u || npend > 0);
         const uint32_t n_node = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(can_node));
         const uint32_t n_tri = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(can_tri));
         if (n_node == 0 && n_tri == 0) {
@@ -191,10 +206,11 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
             for (int rep = 0;; ++rep) {
                 if (STATS && MODE == BVH_AO) { dg[2]++; dg[3] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ct)); }
                 if (ct) {
-                    if (tri_left == 0) {
+                    if ((tri >> 28) == 0u) {
                         const uint32_t ref = pend[(--npend) * RT_BVH_BLOCK];
-                        tri_next = ref & 0x0FFFFFFFu; tri_left = ((ref >> 28) & 7u) + 1u;
+                        tri = (ref & 0x7FFFFFFFu) + 0x10000000u;   // leaf reference: count-1 in bits 28..30 -> count in bits 28..31
                     }
+                    const uint32_t tri_next = tri & 0x0FFFFFFFu;
                     const q4* T = S.tris + (size_t)tri_next * 3;
                     const q4 a = T[0], b = T[1], e = T[2];
                     if (STATS) cnt.tris++;
@@ -211,18 +227,19 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) k_bvh(DScene S, Batch B, int cou
                     const bool ok = !(det < 0.000001f) && !(u < 0 || u > 1) && !(v < 0 || u + v > 1);
                     const uint32_t rank = f2u(e.w);
                     if (MODE == BVH_SHADOW) {   // all-opaque meshes: the first triangle before the light decides, the ray is done
-                        if (ok && t < best.t) { best.prim = H_TRI; sp = 0; npend = 0; tri_left = 1; cur = REF_NONE; }
+                        if (ok && t < best.t) { best.prim = H_TRI; sp = 0; npend = 0; tri = (tri & 0x0FFFFFFFu) | 0x10000000u; cur = REF_NONE; }
                     } else if (MODE == BVH_AO) {   // only the distance leaves this kernel: the reference's first-wins rule on equal t cannot change it
                         if (ok && t < best.t) best.t = t;
                     } else if (ok && closer(t, rank, best)) { best.t = t; best.prim = H_TRI | tri_next; best.u = u; best.v = v; best.rank = rank; }
-                    tri_next++; tri_left--;
+                    tri += 0xF0000001u;   // next slot, one triangle fewer
                 }
                 if (rep == RT_TRI_REPS - 1) break;
-                ct = active && (tri_left > 0 || npend > 0);
+                ct = active && ((tri >> 28) != 0u || npend > 0);
                 if ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ct)) * RT_REP_DEN < n_tri * RT_REP_NUM) break;
             }
         }
     }
+    #undef spill
     constexpr int cls = MODE == BVH_AO ? 2 : MODE == BVH_SHADOW ? 1 : 0;
     flush_counters<STATS>(cnt, B.stats, cls);
     if (STATS) {

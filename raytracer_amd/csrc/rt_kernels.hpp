@@ -12,7 +12,11 @@
 #define RT_MAX_GRID (256 * 8)   // persistent k_bvh, and the default of the grid-stride kernels
 #endif
 #ifndef RT_LDS_STACK
-#define RT_LDS_STACK 14      // k_bvh: stack entries per lane kept in LDS; deeper ones spill to global memory (rare)
+// k_bvh: stack entries per lane kept in LDS; deeper ones spill to global memory.  Round 3: 12 (26 KB per block) so that
+// six blocks fit a CU's 160 KB — with the register diet of rt_bvh.hip / RayCull4 (80 VGPRs, no scratch) the kernel runs
+// 6 waves per SIMD instead of 5: k_bvh<AO> 102.9 -> 98.5 ms on config 3.  Measured around it: 14 entries at 5 waves
+// 102.9, 12 at 5 waves 104.1, 10 at 6 waves 103.6, 10 at 7 waves (3 dwords of scratch) 98.5, 16 at 4 waves 116.7.
+#define RT_LDS_STACK 12
 #endif
 #ifndef RT_BVH_BLOCK
 #define RT_BVH_BLOCK RT_BLOCK   // threads per block and blocks of the persistent kernel (swept 64-512 / 1024-8192: no effect)

@@ -9,8 +9,8 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
-enum { OP_FMA = 0, OP_PK_FMA, OP_PERM, OP_CNDMASK, OP_MIN3, OP_CMP, OP_PK_FMA_F16, OP_MINU, OP_COUNT };
-static const char* names[OP_COUNT] = {"v_fma_f32", "v_pk_fma_f32", "v_perm_b32", "v_cndmask_b32", "v_min3_f32", "v_cmp_lt_f32", "v_pk_fma_f16", "v_min_u32"};
+enum { OP_FMA = 0, OP_PK_FMA, OP_PERM, OP_CNDMASK, OP_MIN3, OP_CMP, OP_PK_FMA_F16, OP_MINU, OP_CND64, OP_CND_INDEP, OP_CMP64, OP_ADD, OP_CND_NOCHAIN64, OP_COUNT };
+static const char* names[OP_COUNT] = {"v_fma_f32", "v_pk_fma_f32", "v_perm_b32", "v_cndmask_b32", "v_min3_f32", "v_cmp_lt_f32", "v_pk_fma_f16", "v_min_u32", "v_cndmask_b32_e64 (sgpr mask, chained)", "v_cndmask_b32 (vcc, dest not a source)", "v_cmp_lt_f32_e64 -> sgpr pair", "v_add_u32", "v_cndmask_b32_e64 (sgpr mask, dest not a source)"};
 
 #define REP8(X) X X X X X X X X
 template <int OP>
@@ -38,6 +38,16 @@ __global__ void __launch_bounds__(256) k_rate(uint64_t* cycles, float* sink, int
             REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %4\n v_cmp_lt_f32 vcc, %1, %4\n v_cmp_lt_f32 vcc, %2, %4\n v_cmp_lt_f32 vcc, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b) : "vcc");)
         } else if (OP == OP_PK_FMA_F16) {
             REP8(asm volatile("v_pk_fma_f16 %0, %0, %4, %5\n v_pk_fma_f16 %1, %1, %4, %5\n v_pk_fma_f16 %2, %2, %4, %5\n v_pk_fma_f16 %3, %3, %4, %5" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(0x3C003C00u), "v"(0x00010001u));)
+        } else if (OP == OP_CND64) {
+            REP8(asm volatile("v_cndmask_b32_e64 %0, %0, %4, s[20:21]\n v_cndmask_b32_e64 %1, %1, %4, s[20:21]\n v_cndmask_b32_e64 %2, %2, %4, s[22:23]\n v_cndmask_b32_e64 %3, %3, %4, s[22:23]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));)
+        } else if (OP == OP_CND_INDEP) {
+            REP8(asm volatile("v_cndmask_b32 %0, %4, %5, vcc\n v_cndmask_b32 %1, %4, %5, vcc\n v_cndmask_b32 %2, %4, %5, vcc\n v_cndmask_b32 %3, %4, %5, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");)
+        } else if (OP == OP_CMP64) {
+            REP8(asm volatile("v_cmp_lt_f32_e64 s[20:21], %0, %4\n v_cmp_lt_f32_e64 s[22:23], %1, %4\n v_cmp_lt_f32_e64 s[24:25], %2, %4\n v_cmp_lt_f32_e64 s[26:27], %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");)
+        } else if (OP == OP_ADD) {
+            REP8(asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(0x11u));)
+        } else if (OP == OP_CND_NOCHAIN64) {
+            REP8(asm volatile("v_cndmask_b32_e64 %0, %4, %5, s[20:21]\n v_cndmask_b32_e64 %1, %4, %5, s[20:21]\n v_cndmask_b32_e64 %2, %4, %5, s[22:23]\n v_cndmask_b32_e64 %3, %4, %5, s[22:23]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));)
         } else {
             REP8(asm volatile("v_min_u32 %0, %0, %4\n v_min_u32 %1, %1, %4\n v_min_u32 %2, %2, %4\n v_min_u32 %3, %3, %4" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(0xFFFFFFF0u));)
         }
@@ -73,7 +83,8 @@ int main()
     CHECK(hipMalloc((void**)&sink, 4));
     for (int w : {1, 2, 4, 8}) {
         if (run<OP_FMA>(w, d_cycles, sink) || run<OP_PK_FMA>(w, d_cycles, sink) || run<OP_PERM>(w, d_cycles, sink) || run<OP_CNDMASK>(w, d_cycles, sink) ||
-            run<OP_MIN3>(w, d_cycles, sink) || run<OP_CMP>(w, d_cycles, sink) || run<OP_PK_FMA_F16>(w, d_cycles, sink) || run<OP_MINU>(w, d_cycles, sink)) return 1;
+            run<OP_MIN3>(w, d_cycles, sink) || run<OP_CMP>(w, d_cycles, sink) || run<OP_PK_FMA_F16>(w, d_cycles, sink) || run<OP_MINU>(w, d_cycles, sink) ||
+            run<OP_CND64>(w, d_cycles, sink) || run<OP_CND_INDEP>(w, d_cycles, sink) || run<OP_CMP64>(w, d_cycles, sink) || run<OP_ADD>(w, d_cycles, sink) || run<OP_CND_NOCHAIN64>(w, d_cycles, sink)) return 1;
     }
     return 0;
 }
