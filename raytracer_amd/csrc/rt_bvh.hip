@@ -44,12 +44,15 @@ using namespace rt;
 // a little).  This kernel's time follows the waves that fit: with LDS padding that leaves 5 / 4 / 3 / 2 waves per SIMD
 // k_bvh<AO> takes 103 / 117 / 143 / 199 ms on config 3 (T ~ 32 + 334 / waves: two thirds of it is memory latency that
 // only more resident waves hide), see DESIGN.md 4.
+// Scenes whose triangles and nodes exceed the Infinity Cache (config 5: 655 MB) are the exception: there the sixth wave
+// costs more in cache misses than it hides (k_bvh<AO> 21.2 ms at 5 waves, 22.4 at 6), so both variants are built and
+// launch_k_bvh picks by DScene::big_scene.
 #ifndef RT_BVH_WAVES
 #define RT_BVH_WAVES 6
 #endif
-#define RT_BVH_ATTR __attribute__((amdgpu_waves_per_eu(RT_BVH_WAVES, RT_BVH_WAVES)))
-template <int MODE, bool STATS>
-__global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR k_bvh(DScene S, Batch B, int counter, int next_counter)
+#define RT_BVH_ATTR(W) __attribute__((amdgpu_waves_per_eu(W, W)))
+template <int MODE, bool STATS, int WAVES>
+__global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR(WAVES) k_bvh(DScene S, Batch B, int counter, int next_counter)
 {
     constexpr bool AO = MODE != BVH_CLOSEST;   // the queue layout of the distance-only queries: no bq_c, bq_cap slots
     // Per-lane stack of {reference, entry distance of its box}, [entry][lane] (conflict-free).  The distance lets
@@ -254,15 +257,15 @@ namespace rt {
 void launch_k_bvh(int mode, bool stats, hipStream_t stream, const DScene& S, const Batch& B, int counter, int next_counter)
 {
     const dim3 grid(RT_BVH_GRID), block(RT_BVH_BLOCK);
-    if (mode == BVH_AO) {
-        if (stats) hipLaunchKernelGGL((k_bvh<BVH_AO, true>), grid, block, 0, stream, S, B, counter, next_counter);
-        else hipLaunchKernelGGL((k_bvh<BVH_AO, false>), grid, block, 0, stream, S, B, counter, next_counter);
-    } else if (mode == BVH_SHADOW) {
-        if (stats) hipLaunchKernelGGL((k_bvh<BVH_SHADOW, true>), grid, block, 0, stream, S, B, counter, next_counter);
-        else hipLaunchKernelGGL((k_bvh<BVH_SHADOW, false>), grid, block, 0, stream, S, B, counter, next_counter);
-    } else {
-        if (stats) hipLaunchKernelGGL((k_bvh<BVH_CLOSEST, true>), grid, block, 0, stream, S, B, counter, next_counter);
-        else hipLaunchKernelGGL((k_bvh<BVH_CLOSEST, false>), grid, block, 0, stream, S, B, counter, next_counter);
-    }
+#define RT_BVH_LAUNCH(M, ST, W) hipLaunchKernelGGL((k_bvh<M, ST, W>), grid, block, 0, stream, S, B, counter, next_counter)
+#define RT_BVH_PICK(M) do { \
+        if (S.big_scene) { if (stats) RT_BVH_LAUNCH(M, true, 5); else RT_BVH_LAUNCH(M, false, 5); } \
+        else { if (stats) RT_BVH_LAUNCH(M, true, RT_BVH_WAVES); else RT_BVH_LAUNCH(M, false, RT_BVH_WAVES); } \
+    } while (0)
+    if (mode == BVH_AO) RT_BVH_PICK(BVH_AO);
+    else if (mode == BVH_SHADOW) RT_BVH_PICK(BVH_SHADOW);
+    else RT_BVH_PICK(BVH_CLOSEST);
+#undef RT_BVH_PICK
+#undef RT_BVH_LAUNCH
 }
 } // namespace rt

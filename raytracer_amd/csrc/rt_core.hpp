@@ -73,10 +73,25 @@ struct DMaterial { int32_t kind; float colour[3]; float kd, ka, ks; int32_t spec
 struct DLight { int32_t kind; float v[3]; float colour[3]; float radiance; };
 struct DTexture { uint32_t offset; int32_t width, height; int32_t set; };
 
+// Compact copy of a gate node for the LDS-resident walk (k_ao_walk_lds, round 3): 16 bytes instead of 48, so that the
+// whole shape-level structure of a scene with thousands of shapes (config 5: 7 500 nodes = 120 KB) sits in a CU's 160 KB
+// of LDS and a gate step costs no global gather unless the node may be entered.
+//   x, y, z : the box as 16-bit grid indices, word a = mn[a] | mx[a] << 16, coordinate = fmaf(q, gq_scale[a], gq_base[a]),
+//             rounded OUTWARDS (verified at build with this very formula): a conservative miss of the decoded box is a
+//             conservative miss of the real one, so it proves the reference's test false exactly as gate_maybe does.
+//             G_MESH | G_SAME_BOX (a MultiMesh's only Mesh: no test of its own): x = the Mesh's triangle-BVH root.
+//   w       : skip (bits 0..23) | kind (bits 24..26) | G_SAME_BOX (bit 27)
+// A box that may be entered is decided on the exact 32-byte box from global memory (gate_surely / box_intersects).
+struct alignas(16) QGate { uint32_t x, y, z, w; };
+#define RT_QGATE_MAX 7680u   // nodes the LDS copy holds (7680 * 16 B = 120 KB); scenes with more use the global walk
+RT_FN float gate_dq(uint32_t q, float scale, float base) { return fmaf((float)q, scale, base); }
+
 #define RT_LEAD_PLANES 8
 struct DScene {
     const GateNode* gates; uint32_t num_gates;
     const GateNode* gates_fast; uint32_t num_gates_fast;   // GPU: the first nodes staged in LDS by the kernel (0 = none)
+    const QGate* qgates; uint32_t num_qgates;              // compact copy of `gates` for the LDS-resident walk (0: none, too many nodes)
+    f3 gq_base, gq_scale;                                  // its grid
     const q4* planes;    // 2 / plane : {point, bits(material)} {normal, 0}
     const q4* spheres;   // 2 / sphere: {centre, radius} {radius^2, bits(material), 0, 0}
     const q4* tris;      // 3 / slot  : {v0, bits(global tri)} {e1=v1-v0, bits(material)} {e2=v2-v0, bits(rank = reference visiting order)}
@@ -87,6 +102,7 @@ struct DScene {
     const DLight* lights; uint32_t num_lights;
     const DTexture* textures; const uint8_t* texels; uint32_t num_textures;
     const uint8_t* item_opaque; uint32_t num_items;  // 1: no transparent material below this scene entry
+    uint32_t big_scene;      // 1: triangles + nodes exceed the 256-MiB Infinity Cache (k_bvh then runs 5 waves per SIMD, not 6)
     uint32_t shadow_defer;   // 1: every Mesh lies in an all-opaque entry: shadow rays queue their meshes for k_bvh<any hit>
     rt_ambient ambient;
     uint32_t prim_base_sphere, prim_base_tri;
@@ -301,9 +317,13 @@ struct RayCull { float sx, sy, sz, lx, ly, lz, hx, hy, hz; };
 //    (the true bound is ~2^-22 of that sum: approximate reciprocal, two products, one fma), subtracted
 //    from the axis' entry distance and added to its exit distance (which plane is which follows from
 //    the sign of d).
-RT_FN RayCull make_cull(const DScene& S, f3 o, f3 d)
+RT_FN RayCull make_cull_grid(float cull_pad, float extent, f3 qbase, f3 qscale, f3 o, f3 d);
+RT_FN RayCull make_cull(const DScene& S, f3 o, f3 d) { return make_cull_grid(S.cull_pad, S.extent, S.qbase, S.qscale, o, d); }
+// the same for any 16-bit grid (the triangle-BVH nodes' grid above, the compact gate nodes' grid: gate_step_q)
+RT_FN RayCull make_cull_grid(float cull_pad, float extent, f3 qbase, f3 qscale, f3 o, f3 d)
 {
     RayCull c;
+    struct { float cull_pad, extent; f3 qbase, qscale; } S = {cull_pad, extent, qbase, qscale};
     float pad = S.cull_pad * (fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) + S.extent);
     float dx = fabsf(d.x) > 1e-20f ? d.x : (d.x < 0 ? -1e-20f : 1e-20f);
     float dy = fabsf(d.y) > 1e-20f ? d.y : (d.y < 0 ? -1e-20f : 1e-20f);
@@ -418,9 +438,10 @@ struct RayCull4 { rt_v2f cx, cy, cz; rt_v2f spx, spy, spz; };
 #define RT_PERM_HI 0x07040302u   // bytes {w.b2, w.b3, 0x00, 0x4B}
 #define RT_PERM_FLIP 0x00000202u
 
-RT_FN RayCull4 make_cull4(const DScene& S, f3 o, f3 d)
+RT_FN RayCull4 make_cull4_from(const RayCull& c);
+RT_FN RayCull4 make_cull4(const DScene& S, f3 o, f3 d) { return make_cull4_from(make_cull(S, o, d)); }
+RT_FN RayCull4 make_cull4_from(const RayCull& c)
 {
-    const RayCull c = make_cull(S, o, d);
     RayCull4 r;
     const float big = 8388608.0f, kd = 0.51f, kc = 1.0f / 1048576.0f;
     // s >= 0 <=> d > 0 (qscale > 0): the lower plane (constant l, already moved earlier) is the entry
@@ -483,6 +504,19 @@ RT_FN bool cull_box4(const RayCull4& rc, uint32_t wx, uint32_t wy, uint32_t wz, 
     const float n = fmaxf(fmaxf(ax, ay), az), f = fminf(fminf(bx, by), bz);
     tnear = n;
     return n <= f && n <= tbest;
+}
+
+// The conservative pre-test of a box GATE (gate_maybe) on a box given as three packed 16-bit words of the compact gate
+// nodes' grid: the same padded slab test over t >= 0, with the per-ray constants of that grid (make_cull_grid with
+// DScene::gq_base / gq_scale; its margins contain gate_maybe's).  False proves the reference's 6-plane test false.
+RT_FN bool gate_maybe4(const RayCull4& rc, uint32_t wx, uint32_t wy, uint32_t wz)
+{
+    float ax, bx, ay, by, az, bz;
+    slab_axis(wx, rc.spx, rc.cx, ax, bx);
+    slab_axis(wy, rc.spy, rc.cy, ay, by);
+    slab_axis(wz, rc.spz, rc.cz, az, bz);
+    const float n = fmaxf(fmaxf(ax, ay), az), f = fminf(fminf(bx, by), bz);
+    return n <= f && f >= 0.0f;
 }
 
 // the four child boxes of a 64-byte node (every slot holds a valid reference: see collapse_node)
@@ -689,6 +723,57 @@ RT_FN uint32_t gate_step(const DScene& S, f3 o, f3 d, const RayGate& rg, uint32_
     }
     return i;
 }
+
+// gate_step for the primitives tested in place only (the caller has dealt with groups and box gates)
+template <bool STATS>
+RT_FN uint32_t gate_step_prim(const DScene& S, f3 o, f3 d, uint32_t i, Hit& best, Counters& cnt)
+{
+    const GateNode g = S.gates[i];
+    const uint32_t kind = g.kind & G_KIND_MASK;
+    float t, u = 0.0f, v = 0.0f;
+    bool hit = false;
+    uint32_t prim = H_MISS;
+    if (kind == G_PLANE) { hit = plane_t(F3(g.mn[0], g.mn[1], g.mn[2]), F3(g.mx[0], g.mx[1], g.mx[2]), o, d, t); prim = H_PLANE | g.a; }
+    else if (kind == G_SPHERE) { hit = sphere_t(F3(g.mn[0], g.mn[1], g.mn[2]), g.mx[0], o, d, t); prim = H_SPHERE | g.a; }
+    else if (kind == G_TRI) {
+        const q4* T = S.tris + (size_t)g.a * 3;
+        const q4 a = T[0], b = T[1], e = T[2];
+        if (STATS) cnt.tris++;
+        hit = tri_t(xyz(a), xyz(b), xyz(e), o, d, t, u, v); prim = H_TRI | g.a;
+    }
+    if (hit && closer(t, g.rank, best)) {
+        best.t = t; best.prim = prim; best.rank = g.rank;
+        if (kind == G_TRI) { best.u = u; best.v = v; }   // planes and spheres leave the record's uv as it was
+    }
+    return i + 1u;
+}
+
+// The same step with the node taken from the compact copy `qg` (QGate: LDS on the GPU).  Box gates are classified from
+// the 16 bytes alone when the decoded (outward-rounded) box is missed; a box that may be entered is decided on the exact
+// box from global memory as in gate_step; planes, spheres and free triangles take gate_step itself.  Same results.
+template <bool STATS>
+RT_FN uint32_t gate_step_q(const DScene& S, const QGate* qg, f3 o, f3 d, const RayGate& rg, const RayCull4& gc, uint32_t i, Hit& best, Stack st, uint32_t& sp, Counters& cnt)
+{
+    const QGate q = qg[i];
+    const uint32_t kind = (q.w >> 24) & 7u;
+    if (kind != G_GATED && kind != G_MESH) return kind == G_GROUP ? i + 1u : gate_step_prim<STATS>(S, o, d, i, best, cnt);
+    if (STATS) cnt.gates++;
+    bool pass = (q.w & (1u << 27)) != 0u;   // G_SAME_BOX: the enclosing gate's test has just passed
+    uint32_t root = q.x;
+    if (!pass && gate_maybe4(gc, q.x, q.y, q.z)) {
+        const GateNode* g = S.gates + i;   // the exact box (and, for a Mesh, its root): 32 / 48 bytes from global memory
+        const q4 b0 = ((const q4*)g)[0], b1 = ((const q4*)g)[1];
+        const float emn[3] = {b0.x, b0.y, b0.z}, emx[3] = {b1.x, b1.y, b1.z};
+        pass = gate_surely(emn, emx, o, d, rg) || box_intersects(emn, emx, o, d);
+        if (pass && kind == G_MESH) root = g->a;
+    }
+    if (kind == G_GATED) return pass ? i + 1u : (q.w & 0xFFFFFFu);
+    if (pass) st.p[(sp++) * st.stride] = root;
+    return i + 1u;
+}
+// (Measured and dropped, round 3: the step split in two — up to 1 / 2 / 3 / 5 hops over nodes that the compact copy
+// decides alone before the lanes meet at the exact test — 58.6 / 53.2 / 57.8 / 69.5 ms against 47.2 for this form on
+// config 5: the extra ballots and the second read of the node cost more than the fuller lanes of the exact test gain.)
 
 template <bool STATS>
 RT_FN uint32_t walk_gates(const DScene& S, f3 o, f3 d, const RayGate& rg, uint32_t i, Hit& best, Stack st, uint32_t& sp, Counters& cnt)

@@ -328,6 +328,109 @@ __global__ void __launch_bounds__(RT_BLOCK) k_ao_walk(DScene S, RenderArgs A, Ba
     flush_counters<STATS>(cnt, B.stats, 2);
 }
 
+// k_ao_walk with the whole gate array resident in LDS as 16-byte compact nodes (QGate, rt_core.hpp) — round 3.
+// k_ao_walk is bound by the texture-address / L1 path (TA busy 77 %): once the lanes of a wave sit on different gate nodes
+// every lane-step is a 48-byte gather of its own cache lines.  Here a step reads 16 bytes from LDS; only a box that the
+// ray may enter (about half of those tested) costs a gather, of the exact 32-byte box that decides it.  One
+// 1024-thread block per CU (16 waves, 4 per SIMD as before) holds 120 KB of nodes + the lanes' root stacks (32 KB) of the
+// CU's 160 KB; scenes with more than RT_QGATE_MAX nodes keep k_ao_walk.  Same items, same results, same queue protocol.
+#define RT_WALKQ_BLOCK 1024
+template <bool STATS>
+__global__ void __launch_bounds__(RT_WALKQ_BLOCK) k_ao_walk_lds(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
+{
+    __shared__ uint32_t s_stack[RT_DEFER_ROOTS * RT_WALKQ_BLOCK];
+    __shared__ QGate s_q[RT_QGATE_MAX];
+    for (uint32_t k = threadIdx.x; k < S.num_qgates; k += RT_WALKQ_BLOCK) s_q[k] = S.qgates[k];
+    __syncthreads();
+    const uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
+    const uint32_t nslots = depth == 0 ? fixed_n : B.counters[C_QUEUE + depth];
+    const uint32_t n = nslots * n2;
+    const uint32_t waves = gridDim.x * (RT_WALKQ_BLOCK / 64);
+    const uint32_t lane = threadIdx.x & 63u;
+    if ((uint64_t)(blockIdx.x * (RT_WALKQ_BLOCK / 64) + (threadIdx.x >> 6)) * 64u >= n) return;   // more waves than groups of 64 items (no barrier follows)
+    uint32_t next = 0, end = 0;   // wave-uniform: the claimed range of items still to hand out
+    bool exhausted = false;
+    Stack st{s_stack + threadIdx.x, RT_WALKQ_BLOCK};
+    Counters cnt{0, 0, 0, 0};
+    QCursor qc{0, 0, queue_chunk(n, waves, RT_QCHUNK)};
+    const uint32_t ng = S.num_gates;
+    bool active = false;
+    f3 o = F3(0, 0, 0), dir = F3(0, 0, 1);
+    RayGate rg = {};
+    RayCull4 gc = {};   // the ray's constants on the compact gate nodes' grid
+    Hit h; h.t = 0; h.prim = H_MISS; h.u = 0; h.v = 0; h.rank = 0;
+    uint32_t dst = 0, sp = 0, i = ng, item = 0, slot_of = 0;
+    for (;;) {
+        // ---- rays whose walk ended or whose root stack is full: queue item, distance ----
+        const bool done = active && i >= ng;
+        const bool want = active && sp > 0 && (done || sp >= RT_DEFER_ROOTS);
+        const uint32_t slot = chunk_append<RT_QCHUNK>(&B.counters[C_BQA + depth], want, qc, B.bq_roots, (uint32_t)REF_NONE, B.bq_cap);
+        if (want) {
+            if (slot < B.bq_cap) {
+                const q4 a = {o.x, o.y, o.z, h.t};
+                const q4 b = {dir.x, dir.y, dir.z, u2f(bq_word(dst, sp))};
+                B.bq_a[slot] = a; B.bq_b[slot] = b;
+                bq_store_roots(B, slot, st, sp);
+            } else {   // queue full: all rays of the 64 AO slots around this ray's are redone by k_ao_overflow (entered once)
+                const uint32_t g = slot_of >> 6;
+                if (!(atomicOr(&B.ovf_bits[g >> 5], 1u << (g & 31u)) & (1u << (g & 31u)))) {
+                    const uint32_t e = atomicAdd(&B.counters[C_AO + depth], 1u);
+                    if (e < B.ovf_cap) B.ao_ovf[e] = g << 6;
+                }
+            }
+            sp = 0;
+        }
+        if (done) { B.ao_key[dst] = t_key(h.t); active = false; }
+        // ---- refill ----
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(!active);
+        const uint32_t nidle = (uint32_t)__popcll(idle);
+        if (next >= end && !exhausted && nidle >= RT_WALK_REFILL) {   // claim the next RT_WALK_CHUNK items (whole groups of 64)
+            uint32_t b0 = 0;
+            if (lane == 0) b0 = atomicAdd(&B.counters[C_AOW + depth], (uint32_t)RT_WALK_CHUNK);
+            b0 = __shfl(b0, 0);
+            next = b0 < n ? b0 : n; end = b0 + RT_WALK_CHUNK < n ? b0 + RT_WALK_CHUNK : n;
+            exhausted = b0 >= n || n - b0 <= RT_WALK_CHUNK;   // n < 2^31: no wrap
+        }
+        if (next < end && nidle >= RT_WALK_REFILL) {
+            const uint32_t mine = next + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!active && mine < end) {
+                item = mine;
+                uint32_t slot_ao, k;
+                ao_coords(S, nslots, item & ~255u, item & 255u, slot_ao, k);
+                const q4 rw = B.ao_w[slot_ao];
+                if (f2u(rw.w) != 0xFFFFFFFFu) {   // else: a path without AO rays
+                    const q4 ro = B.ao_o[slot_ao], ru = B.ao_u[slot_ao];
+                    cnt.rays++;
+                    o = xyz(ro);
+                    dir = ao_dir(S.ambient, xyz(ru), xyz(rw), f2u(ro.w), f2u(rw.w), k);
+                    dst = (uint32_t)ao_index(B, slot_ao, k);
+                    slot_of = slot_ao;
+                    rg = make_gate(S.cull_pad, S.extent, o, dir);
+                    gc = make_cull4_from(make_cull_grid(S.cull_pad, S.extent, S.gq_base, S.gq_scale, o, dir));
+                    h.t = S.ambient.occlusion_dist; h.prim = H_MISS; h.rank = 0;
+                    i = (S.debug & 2u) ? ng : lead_planes_hit(S, o, dir, rg, h);
+                    sp = 0;
+                    active = true;
+                }
+            }
+            next = next + nidle < end ? next + nidle : end;
+        }
+        if (__builtin_amdgcn_ballot_w64(active) == 0ull) {
+            if (next >= end && exhausted) break;
+            continue;
+        }
+        // ---- RT_WALK_REPS gate nodes per lane ----
+#pragma nounroll
+        for (int rep = 0; rep < RT_WALK_REPS; ++rep) {
+            const bool go = active && i < ng && sp < RT_DEFER_ROOTS;
+            if (__builtin_amdgcn_ballot_w64(go) == 0ull) break;
+            if (go) i = gate_step_q<STATS>(S, s_q, o, dir, rg, gc, i, h, st, sp, cnt);
+        }
+    }
+    close_cursor(qc, B.bq_roots, (uint32_t)REF_NONE, B.bq_cap);
+    flush_counters<STATS>(cnt, B.stats, 2);
+}
+
 template <bool STATS>
 __global__ void __launch_bounds__(RT_OVF_BLOCK) k_ao_overflow(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
 {
@@ -600,6 +703,13 @@ struct GpuBackend {
             // its "group already entered in the overflow list" bits hold for ONE launch (one depth level of one batch)
             hipError_t r = hipMemsetAsync(B.ovf_bits, 0, ovf_bits_bytes, stream);
             if (r != hipSuccess) err = r;
+            if (S.num_qgates && !(S.debug & 64u)) {   // the whole gate array fits LDS: one 1024-thread block per CU
+                timed(RT_K_AO, [&] {
+                    if (stats) hipLaunchKernelGGL(k_ao_walk_lds<true>, dim3(256), dim3(RT_WALKQ_BLOCK), 0, stream, S, A, B, d, n);
+                    else hipLaunchKernelGGL(k_ao_walk_lds<false>, dim3(256), dim3(RT_WALKQ_BLOCK), 0, stream, S, A, B, d, n);
+                });
+                return;
+            }
             const uint32_t gw = grid_many((uint64_t)n * (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples), d == 0 ? RT_GRID_AO_WALK : RT_MAX_GRID);
             timed(RT_K_AO, [&] {
                 if (stats) hipLaunchKernelGGL(k_ao_walk<true>, dim3(gw), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
@@ -910,12 +1020,20 @@ int rt_scene_commit(rt_scene* s)
     if ((rc = up(H.dtextures.data(), H.dtextures.size() * sizeof(DTexture), (const void**)&D.textures))) return rc;
     if ((rc = up(H.texels.data(), H.texels.size(), (const void**)&D.texels))) return rc;
     if ((rc = up(H.item_opaque.data(), H.item_opaque.size(), (const void**)&D.item_opaque))) return rc;
+    if ((rc = up(H.qgates.data(), H.qgates.size() * sizeof(QGate), (const void**)&D.qgates))) return rc;
+    D.num_qgates = (uint32_t)H.qgates.size();
+    D.gq_base = F3(H.gq_base[0], H.gq_base[1], H.gq_base[2]); D.gq_scale = F3(H.gq_scale[0], H.gq_scale[1], H.gq_scale[2]);
     D.num_gates = (uint32_t)H.gates.size();
     D.gates_fast = nullptr; D.num_gates_fast = 0;
     D.num_lights = (uint32_t)H.dlights.size();
     D.num_textures = (uint32_t)H.dtextures.size();
     D.num_items = (uint32_t)H.item_opaque.size();
     D.shadow_defer = H.shadow_defer ? 1u : 0u;
+    {   // bytes of triangle records + nodes the traversal gathers from (host-built or device-built)
+        const size_t tri_bytes = lb_tris ? (size_t)H.gpu_slots * 3 * sizeof(q4) : H.tris4.size() * sizeof(q4);
+        const size_t node_bytes = lb_nodes ? (size_t)H.gpu_nodes * 4 * sizeof(q4) : H.nodes4.size() * sizeof(q4);
+        D.big_scene = tri_bytes + node_bytes > (256ull << 20) ? 1u : 0u;
+    }
     D.ambient = H.ambient;
     D.prim_base_sphere = (uint32_t)H.planes.size();
     D.prim_base_tri = (uint32_t)(H.planes.size() + H.spheres.size());

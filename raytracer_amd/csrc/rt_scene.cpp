@@ -564,6 +564,51 @@ void HostScene::quantize_nodes()
     });
 }
 
+// The 16-byte copies of the gate nodes (QGate, rt_core.hpp): boxes on a 16-bit grid over the union of the gate boxes,
+// rounded outwards and checked with the kernels' own decode (gate_dq).
+void HostScene::build_qgates()
+{
+    qgates.clear();
+    if (gates.size() > RT_QGATE_MAX || gates.size() >= (1u << 24)) return;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    auto boxed = [](const GateNode& g) { const uint32_t k = g.kind & G_KIND_MASK; return (k == G_GATED || k == G_MESH) && !(g.kind & G_SAME_BOX); };
+    for (const GateNode& g : gates) {
+        if (!boxed(g)) continue;
+        for (int a = 0; a < 3; ++a) {
+            if (!(std::isfinite(g.mn[a]) && std::isfinite(g.mx[a]) && g.mn[a] <= g.mx[a])) return;   // not a box a grid can hold: global walk
+            mn[a] = std::min(mn[a], g.mn[a]); mx[a] = std::max(mx[a], g.mx[a]);
+        }
+    }
+    for (int a = 0; a < 3; ++a) {
+        if (!(mn[a] <= mx[a])) { mn[a] = 0.0f; mx[a] = 1.0f; }
+        gq_base[a] = mn[a];
+        gq_scale[a] = std::max((mx[a] - mn[a]) / 65533.0f, 1e-30f);
+    }
+    qgates.resize(gates.size());
+    for (size_t i = 0; i < gates.size(); ++i) {
+        const GateNode& g = gates[i];
+        const uint32_t kind = g.kind & G_KIND_MASK;
+        QGate q{0, 0, 0, 0};
+        q.w = (g.skip & 0xFFFFFFu) | (kind << 24) | ((g.kind & G_SAME_BOX) ? (1u << 27) : 0u);
+        if (boxed(g)) {
+            uint32_t w[3];
+            for (int a = 0; a < 3; ++a) {
+                const double l = std::floor(((double)g.mn[a] - (double)gq_base[a]) / (double)gq_scale[a]) - 1.0;
+                const double h = std::ceil(((double)g.mx[a] - (double)gq_base[a]) / (double)gq_scale[a]) + 1.0;
+                uint32_t ql = (uint32_t)std::min(65535.0, std::max(0.0, l)), qh = (uint32_t)std::min(65535.0, std::max(0.0, h));
+                while (ql > 0 && gate_dq(ql, gq_scale[a], gq_base[a]) > g.mn[a]) --ql;
+                while (qh < 65535 && gate_dq(qh, gq_scale[a], gq_base[a]) < g.mx[a]) ++qh;
+                if (gate_dq(ql, gq_scale[a], gq_base[a]) > g.mn[a] || gate_dq(qh, gq_scale[a], gq_base[a]) < g.mx[a]) { qgates.clear(); return; }   // cannot enclose it
+                w[a] = ql | (qh << 16);
+            }
+            q.x = w[0]; q.y = w[1]; q.z = w[2];
+        } else if (kind == G_MESH) {
+            q.x = g.a;   // G_SAME_BOX: entered without a test, only the root is needed
+        }
+        qgates[i] = q;
+    }
+}
+
 void HostScene::emit_mesh(uint32_t mesh, uint32_t item, uint32_t rank_base)
 {
     GateNode g{};
@@ -800,6 +845,7 @@ int HostScene::build()
     } else
     quantize_nodes();
     mesh_part_.clear(); mesh_part_.shrink_to_fit();
+    build_qgates();
     if (timing) std::fprintf(stderr, "[rt_scene] reference hierarchies alone %.3f s\n", hierarchy_seconds_);
     if (timing) std::fprintf(stderr, "[rt_scene] triangle BVHs %.3f s, gate emission (reference hierarchies) %.3f s, node / triangle record copies %.3f s, node quantisation %.3f s\n",
                              secs(t_begin, t_parts), secs(t_parts, t_walk), secs(t_walk, t_emit), secs(t_emit, now()));

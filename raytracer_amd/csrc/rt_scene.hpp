@@ -32,6 +32,9 @@ struct HostScene {
 
     // ---- flattened form (what gets uploaded) ----
     std::vector<GateNode> gates;
+    std::vector<QGate> qgates;          // compact copy for the LDS-resident gate walk (empty: more than RT_QGATE_MAX nodes)
+    float gq_base[3] = {0, 0, 0}, gq_scale[3] = {1, 1, 1};
+    void build_qgates();
     std::vector<q4> planes4, spheres4, tris4, attr4, nodes4;
     std::vector<q4> fnodes4;            // build-time float nodes (4 q4 each, two-wide); nodes4 holds the quantised four-wide nodes (4 q4 each)
     float qbase[3] = {0, 0, 0}, qscale[3] = {1, 1, 1};   // node grid: coordinate = qbase + q * qscale

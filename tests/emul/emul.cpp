@@ -92,6 +92,24 @@ struct LoopBackend {
 };
 } // namespace
 
+static void fill_scene(const HostScene& H, DScene& S)
+{
+    S = DScene{};
+    S.gates = H.gates.data(); S.num_gates = (uint32_t)H.gates.size(); S.gates_fast = nullptr; S.num_gates_fast = 0;
+    S.qgates = H.qgates.data(); S.num_qgates = (uint32_t)H.qgates.size();
+    S.gq_base = F3(H.gq_base[0], H.gq_base[1], H.gq_base[2]); S.gq_scale = F3(H.gq_scale[0], H.gq_scale[1], H.gq_scale[2]);
+    S.planes = H.planes4.data(); S.spheres = H.spheres4.data(); S.tris = H.tris4.data();
+    S.tri_attr = H.attr4.data(); S.nodes = H.nodes4.data();
+    S.materials = H.dmaterials.data(); S.lights = H.dlights.data(); S.num_lights = (uint32_t)H.dlights.size();
+    S.textures = H.dtextures.data(); S.texels = H.texels.data(); S.num_textures = (uint32_t)H.dtextures.size();
+    S.item_opaque = H.item_opaque.data(); S.num_items = (uint32_t)H.item_opaque.size(); S.shadow_defer = H.shadow_defer ? 1u : 0u;
+    S.ambient = H.ambient;
+    S.prim_base_sphere = (uint32_t)H.planes.size(); S.prim_base_tri = (uint32_t)(H.planes.size() + H.spheres.size());
+    S.cull_pad = 1.0f / 262144.0f; S.extent = H.extent; S.debug = 0;
+    H.fill_lead_planes(S);
+    S.qbase = F3(H.qbase[0], H.qbase[1], H.qbase[2]); S.qscale = F3(H.qscale[0], H.qscale[1], H.qscale[2]);
+}
+
 extern "C" {
 
 static std::string g_err;
@@ -119,17 +137,7 @@ int emul_render(const rt_scene_desc* d, const rt_camera* cam, const rt_params* p
 
     LoopBackend be;
     DScene& S = be.S;
-    S.gates = H.gates.data(); S.num_gates = (uint32_t)H.gates.size(); S.gates_fast = nullptr; S.num_gates_fast = 0;
-    S.planes = H.planes4.data(); S.spheres = H.spheres4.data(); S.tris = H.tris4.data();
-    S.tri_attr = H.attr4.data(); S.nodes = H.nodes4.data();
-    S.materials = H.dmaterials.data(); S.lights = H.dlights.data(); S.num_lights = (uint32_t)H.dlights.size();
-    S.textures = H.dtextures.data(); S.texels = H.texels.data(); S.num_textures = (uint32_t)H.dtextures.size();
-    S.item_opaque = H.item_opaque.data(); S.num_items = (uint32_t)H.item_opaque.size(); S.shadow_defer = H.shadow_defer ? 1u : 0u;
-    S.ambient = H.ambient;
-    S.prim_base_sphere = (uint32_t)H.planes.size(); S.prim_base_tri = (uint32_t)(H.planes.size() + H.spheres.size());
-    S.cull_pad = 1.0f / 262144.0f; S.extent = H.extent; S.debug = 0;
-    H.fill_lead_planes(S);
-    S.qbase = F3(H.qbase[0], H.qbase[1], H.qbase[2]); S.qscale = F3(H.qscale[0], H.qscale[1], H.qscale[2]);
+    fill_scene(H, S);
 
     RenderArgs A{};
     A.cam = make_camera(*cam);
@@ -258,5 +266,83 @@ int emul_gate_check(uint32_t n, uint32_t seed, double* out)
 
 // chunk size a launch takes for its queue appends (rt_pipeline.hpp)
 uint32_t emul_queue_chunk(unsigned long long appends, uint32_t waves, uint32_t largest) { return queue_chunk(appends, waves, largest); }
+
+// The gate walk from the compact LDS copy of the gate nodes (gate_step_q: k_ao_walk_lds) against the walk over the full
+// nodes (gate_step), ray by ray: same visiting sequence, same closest primitive, same mesh roots in the same order.
+// Rays: random origins inside / around the scene, random directions, plus rays aimed at box corners, edges and faces of
+// the gate boxes (where a conservative classification is most likely to go wrong) and rays starting on box planes.
+// out = {rays, gate steps, steps the 16-byte copy decided without the exact box, mismatches, nodes in the copy}
+int emul_qgate_compare(const rt_scene_desc* d, uint32_t nrays, uint32_t seed, unsigned long long* out)
+{
+    HostScene H;
+    H.planes.assign(d->planes, d->planes + d->num_planes);
+    H.spheres.assign(d->spheres, d->spheres + d->num_spheres);
+    H.triangles.assign(d->triangles, d->triangles + d->num_triangles);
+    H.meshes.assign(d->meshes, d->meshes + d->num_meshes);
+    H.multimeshes.assign(d->multimeshes, d->multimeshes + d->num_multimeshes);
+    H.bvhs.assign(d->bvhs, d->bvhs + d->num_bvhs);
+    H.bvh_leaves.assign(d->bvh_leaves, d->bvh_leaves + d->num_bvh_leaves);
+    H.scene.assign(d->scene, d->scene + d->num_scene);
+    H.materials.assign(d->materials, d->materials + d->num_materials);
+    H.textures.assign(d->textures, d->textures + d->num_textures);
+    H.lights.assign(d->lights, d->lights + d->num_lights);
+    H.ambient = d->ambient;
+    int rc = H.build();
+    if (rc) { g_err = H.error; return rc; }
+    DScene S;
+    fill_scene(H, S);
+    out[0] = out[1] = out[2] = out[3] = 0; out[4] = S.num_qgates;
+    if (!S.num_qgates) return 0;
+    std::vector<uint32_t> boxed;
+    for (uint32_t i = 0; i < S.num_gates; ++i) { const uint32_t k = S.gates[i].kind & G_KIND_MASK; if (k == G_GATED || k == G_MESH) boxed.push_back(i); }
+    uint64_t rng = 0x9E3779B97F4A7C15ull ^ ((uint64_t)seed << 17);
+    auto u01 = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (float)((rng >> 40) * (1.0 / 16777216.0)); };
+    const float E = S.extent > 0 ? S.extent : 1.0f;
+    std::vector<uint32_t> stack_a(RT_DEFER_ROOTS + 1), stack_b(RT_DEFER_ROOTS + 1), roots_a, roots_b;
+    for (uint32_t r = 0; r < nrays; ++r) {
+        f3 o = F3((u01() * 2 - 1) * E * 1.1f, (u01() * 2 - 1) * E * 1.1f, (u01() * 2 - 1) * E * 1.1f);
+        f3 t = F3((u01() * 2 - 1) * E, (u01() * 2 - 1) * E, (u01() * 2 - 1) * E);
+        const uint32_t mode = r % 4u;
+        if (mode != 0 && !boxed.empty()) {   // aim at a feature of a gate box
+            const GateNode& g = S.gates[boxed[(size_t)(u01() * boxed.size()) % boxed.size()]];
+            auto pick = [&](int a) { const float w = u01(); return w < 0.4f ? g.mn[a] : (w < 0.8f ? g.mx[a] : g.mn[a] + (g.mx[a] - g.mn[a]) * u01()); };
+            t = F3(pick(0), pick(1), pick(2));
+            if (mode == 3) { o = F3(pick(0), pick(1), pick(2)); t = F3((u01() * 2 - 1) * E, (u01() * 2 - 1) * E, (u01() * 2 - 1) * E); }   // origin on the box
+        }
+        f3 dir = t - o;
+        if (!(dot(dir, dir) > 0.0f)) continue;
+        dir = normalize(dir);
+        if (r % 16u == 5u) dir.y = 0.0f;               // axis-parallel components
+        if (r % 16u == 9u) { dir.x = 0.0f; dir.z = 1e-6f; }
+        const RayGate rg = make_gate(S.cull_pad, S.extent, o, dir);
+        const RayCull4 gc = make_cull4_from(make_cull_grid(S.cull_pad, S.extent, S.gq_base, S.gq_scale, o, dir));
+        Hit ha, hb;
+        ha.t = hb.t = 1000.0f; ha.prim = hb.prim = H_MISS; ha.u = ha.v = hb.u = hb.v = 0; ha.rank = hb.rank = 0;
+        Counters ca{0, 0, 0, 0}, cb{0, 0, 0, 0};
+        uint32_t ia = lead_planes_hit(S, o, dir, rg, ha), ib = lead_planes_hit(S, o, dir, rg, hb), spa = 0, spb = 0;
+        roots_a.clear(); roots_b.clear();
+        bool bad = false;
+        while (ia < S.num_gates || ib < S.num_gates) {
+            if (ia != ib) { bad = true; break; }
+            const uint32_t k = (S.qgates[ib].w >> 24) & 7u;
+            const uint32_t i0 = ib;
+            ia = gate_step<true>(S, o, dir, rg, ia, ha, Stack{stack_a.data(), 1}, spa, ca);
+            ib = gate_step_q<true>(S, S.qgates, o, dir, rg, gc, ib, hb, Stack{stack_b.data(), 1}, spb, cb);
+            out[1]++;
+            if (k == G_GATED || k == G_MESH) {   // decided from the 16 bytes alone: flagged as same box, or the decoded box was missed
+                const QGate q = S.qgates[i0];
+                const bool from_q = (q.w & (1u << 27)) != 0u || !gate_maybe4(gc, q.x, q.y, q.z);
+                if (from_q) out[2]++;
+            }
+            for (uint32_t k2 = 0; k2 < spa; ++k2) roots_a.push_back(stack_a[k2]);
+            for (uint32_t k2 = 0; k2 < spb; ++k2) roots_b.push_back(stack_b[k2]);
+            spa = spb = 0;
+        }
+        if (!bad) bad = ia != ib || roots_a != roots_b || f2u(ha.t) != f2u(hb.t) || ha.prim != hb.prim || ha.rank != hb.rank || ca.gates != cb.gates;
+        out[0]++;
+        if (bad) out[3]++;
+    }
+    return 0;
+}
 
 } // extern "C"

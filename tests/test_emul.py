@@ -159,3 +159,19 @@ def test_queue_chunk_properties(emul):
     assert f(33_423_360, 6144, 512) == 512          # k_prep, config 3: 1536 blocks of 4 waves
     assert f(534_773_760, 131072, 1024) == 512      # k_ao, config 3: 32768 blocks
     assert f(2_000_000, 8192, 1024) == 64           # a small frame
+
+
+def test_compact_gate_walk_equals_the_full_one(emul):
+    """k_ao_walk_lds walks 16-byte copies of the gate nodes (boxes on a 16-bit grid, rounded outwards) out of LDS and
+    fetches the exact box only when the decoded one may be entered (gate_step_q, rt_core.hpp).  On an instanced scene
+    (config 5's structure: a BVHAccel over hundreds of MultiMeshes) and on the reference's own scene, random rays and
+    rays aimed at the corners / edges / faces of the gate boxes take the same walk as with the full nodes: same
+    sequence of nodes, same closest primitive, same mesh roots."""
+    w = scenes.config5_scene(64, 48, 1, instances=300, mesh_nu=6, mesh_nv=4)
+    rays, steps, from_q, bad, n = emul.qgate_compare(w.flatten(), 60000, seed=3)
+    assert n > 600 and rays > 59000
+    assert bad == 0
+    assert from_q > 0.3 * steps   # the compact copy alone decides a good part of the steps (misses + same-box gates)
+    w = scenes.default_scene(64, 48, mesh_nu=8, mesh_nv=4)
+    rays, steps, from_q, bad, n = emul.qgate_compare(w.flatten(), 40000, seed=5)
+    assert n > 0 and bad == 0

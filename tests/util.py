@@ -32,6 +32,16 @@ class Emul:
             raise RuntimeError(f"emul_render failed ({rc}): {self.lib.emul_last_error().decode()}")
         return rgb, pid, t, cnt
 
+    def qgate_compare(self, flat, nrays, seed=1):
+        """gate_step_q (compact LDS gate nodes) against gate_step on random + adversarial rays:
+        {rays, steps, decided from the compact copy, mismatches, nodes in the copy}"""
+        out = np.zeros(5, np.uint64)
+        self.lib.emul_qgate_compare.argtypes = [C.POINTER(capi.rt_scene_desc), C.c_uint32, C.c_uint32, C.c_void_p]
+        rc = self.lib.emul_qgate_compare(C.byref(flat.desc), nrays, seed, out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"emul_qgate_compare failed ({rc}): {self.lib.emul_last_error().decode()}")
+        return [int(x) for x in out]
+
     def bvh_dump(self, flat, which=0, cap=4096):
         out = np.zeros((cap, 9), np.float32)
         n = self.lib.emul_bvh_dump(C.byref(flat.desc), which, out.ctypes.data, cap)
