@@ -186,11 +186,25 @@ __global__ void __launch_bounds__(RT_OVF_BLOCK) k_shadow_overflow(DScene S, Rend
 // The hot AO kernel traverses nothing (ao_item): a stack of RT_DEFER_ROOTS mesh roots per lane is all it needs.
 // One lane = one hit and its n*n rays in turn (the AO frame, 48 bytes, is read once per hit; as one item per ray in a
 // blocked stratum-major order the bare item loop — decode, three loads, one store — was 15 of the kernel's 46 ms).
+// Round 3: k_ao runs 5 waves per SIMD (96 VGPRs, no scratch) instead of 4.  Its time follows the waves that fit — with LDS
+// padding that leaves 4 / 3 / 2 waves per SIMD it takes 39.7 / 47.8 / 65.8 ms on config 3 (T ~ 12 + 108 / waves) — and what
+// had held it at 118 VGPRs was not its own state: the compiler hoisted the 17 fp64 constants of the AO direction
+// (sincos_f64, div_rand_max) out of the stratum loop into 34 vector registers that stayed live through the gate walk.
+// They now arrive through scalar registers (RT_K64, rt_core.hpp): 98 VGPRs, 96 under this cap: 39.6 -> 36.3 ms.
+// At 6 waves (80 VGPRs) 15 dwords spill and the kernel takes 42.7 ms.
+#ifndef RT_AO_WAVES
+#define RT_AO_WAVES 5
+#endif
+#define RT_AO_ATTR __attribute__((amdgpu_waves_per_eu(RT_AO_WAVES, RT_AO_WAVES)))
 template <bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK) k_ao(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
+__global__ void __launch_bounds__(RT_BLOCK) RT_AO_ATTR k_ao(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
 {
     __shared__ uint32_t s_stack[RT_DEFER_ROOTS * RT_BLOCK];
     __shared__ GateNode s_gates[RT_LDS_GATES];
+#ifdef RT_AO_LDS_PAD   // experiment: fewer resident waves (issue- or latency-bound?)
+    __shared__ uint32_t s_pad[RT_AO_LDS_PAD / 4];
+    if (depth == 0x7FFFFFFF) s_pad[threadIdx.x] = 1u;
+#endif
     stage_gates(S, s_gates);
     const uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
     const uint32_t nslots = depth == 0 ? fixed_n : B.counters[C_QUEUE + depth];

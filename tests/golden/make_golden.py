@@ -69,6 +69,25 @@ def converged_random(ref, runs=32):
     print("converged (Random sampler): single-run PSNR against the mean of the others %.2f dB (min %.2f)" % (np.mean(loo), np.min(loo)))
 
 
+def regular4_scene():
+    """The reference's main() scene with Regular(4, 1) — the one multi-sample mode in which the reference's OWN Sampler
+    (Sampler::sampleUnitSquare over Regular::generateSamples, main.cpp:539-548, 971-991) is deterministic up to the
+    order of the four samples — flat ambient (no AO, so no rand() in shading)."""
+    from raytracer_amd import scene as S, scenes
+    w = scenes.default_scene(160, 120, sampler=S.Regular(4, 1), ao_samples=0)
+    return w, w.params(seed=1)
+
+
+def regular4(ref):
+    """default_regular4.npz: rendered by the real reference through its own sampler (harness rng_mode 2 routes every
+    sample through sampler->sampleUnitSquare(); one thread, as SURVEY 8c prescribes for the shared Sampler)."""
+    w, p = regular4_scene()
+    r = ref.render(w.flatten(), w.camera, p, rng_mode=2, nthreads=1, ids=False)
+    np.savez_compressed(os.path.join(HERE, "default_regular4.npz"), rgb=r.rgb, rays=np.uint64(r.rays),
+                        params=np.frombuffer(bytes(p), dtype=np.uint8))
+    print("default_regular4", r.rgb.shape, "rays", r.rays)
+
+
 def bmp_inputs():
     """Float images for the saveToFile fixtures: widths 200 and 101 (row padding 0 and 1 bytes), a 4x4 image
     (fewer pixels than header bytes) and a 3x5 one (3 bytes of padding).  Values in [0,1] with the exact
@@ -152,6 +171,9 @@ def main():
     if sys.argv[1:] == ["bmp"]:
         bmp(ref)
         return
+    if sys.argv[1:] == ["regular4"]:
+        regular4(ref)
+        return
     only = set(sys.argv[2:]) if sys.argv[1:2] == ["only"] else None   # `only name ...`: just these scene fixtures
     for name, world, params in util.small_scenes():
         if only is not None and name not in only:
@@ -166,6 +188,7 @@ def main():
         return
     bmp(ref)
     cpp_host(ref)
+    regular4(ref)
 
     # known-answer vectors of single functions
     rng = np.random.default_rng(1234)

@@ -42,6 +42,34 @@ def test_device_code_on_host_matches_reference_fixture(emul, name, world, params
     assert int(cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[13]) == int(g["rays"])
 
 
+def _regular4():
+    # only the scene definition is needed: it lives beside the generator so that fixture and tests cannot drift apart
+    src = open(os.path.join(util.GOLDEN, "make_golden.py")).read()
+    ns = {}
+    start = src.index("def regular4_scene():")
+    exec(src[start:src.index("def regular4(ref):")], ns)
+    return ns["regular4_scene"]()
+
+
+def test_regular_multisample_through_the_reference_sampler(port, emul):
+    """a3: Regular(4, 1) rendered by the reference through its OWN Sampler::sampleUnitSquare (harness rng_mode 2,
+    one thread) — the sample points are Regular::generateSamples' (main.cpp:971-991), only their order within a pixel
+    is shuffled, which permutes the terms of the pixel sum: the oracle restatement and the device code (both walk the
+    strata in order) agree with it within 1 LSB of the 8-bit image, and trace exactly as many rays."""
+    g = load("default_regular4")
+    w, p = _regular4()
+    assert bytes(g["params"].tobytes()) == bytes(p)
+    flat = w.flatten()
+    r = port.render(flat, w.camera, p, rng_mode=1, nthreads=4, ids=False)
+    assert util.lsb_diff(r.rgb, g["rgb"]).max() <= 1
+    assert r.rays == int(g["rays"])
+    rgb, prim, t, cnt = emul.render(flat, w.camera, p)
+    assert util.lsb_diff(rgb, g["rgb"]).max() <= 1
+    assert int(cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[13]) == int(g["rays"])
+    # the float images differ only by the summation order: a few ulps
+    assert np.abs(rgb - g["rgb"]).max() < 1e-6
+
+
 def test_known_answer_vectors(port):
     k = np.load(os.path.join(util.GOLDEN, "kat.npz"))
     L = port.lib

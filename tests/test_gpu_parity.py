@@ -160,6 +160,23 @@ def test_matches_reference_fixture(gpu, name, world, params, builder):
     assert st.rays_reference_unit == int(g["rays"])
 
 
+def test_regular_multisample_matches_the_reference_sampler(gpu):
+    """a3: tests/golden/default_regular4.npz was rendered by the real reference through its OWN Sampler (Regular(4, 1),
+    Sampler::sampleUnitSquare, main.cpp:539-548, 971-991; harness rng_mode 2, one thread): same sample points, shuffled
+    order within the pixel.  The GPU frame is within 1 LSB (in fact within a few ulps: only the order of the four-term
+    sum differs) and counts the same rays."""
+    import os
+    from test_golden import _regular4
+    g = np.load(os.path.join(util.GOLDEN, "default_regular4.npz"))
+    w, p = _regular4()
+    assert bytes(g["params"].tobytes()) == bytes(p)
+    gpu.upload(w)
+    rgb, _, _, st = gpu.render(w.camera, p)
+    assert util.lsb_diff(rgb, g["rgb"]).max() <= 1
+    assert np.abs(rgb - g["rgb"]).max() < 1e-6
+    assert st.rays + st.rays_skipped == int(g["rays"])
+
+
 @pytest.fixture(scope="module")
 def config3_full(gpu):
     """BASELINE.json config 3 at full size: 3840x2160, 16 jittered spp, 4x4 AO, ~0.5 M-triangle mesh."""

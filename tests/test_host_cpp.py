@@ -15,8 +15,10 @@ from raytracer_amd import scenes, scene as S
 EXE = os.path.join(conftest.ROOT, "examples", "default_scene")
 
 
-def write_model_dir(root):
-    """models/teapot/{teapot.obj, default.mtl, default.ppm}: the procedural stand-in for the absent teapot.obj."""
+def write_model_dir(root, png_backslash=False):
+    """models/teapot/{teapot.obj, default.mtl, default.ppm}: the procedural stand-in for the absent teapot.obj.
+    png_backslash: the texture as a PNG in a sub-directory, named in the MTL with a backslash path the way the
+    reference's models/sponza/sponza.mtl names its textures (map_Kd textures\\sponza_thorn_diff.png)."""
     d = os.path.join(root, "teapot")
     os.makedirs(d, exist_ok=True)
     tex = scenes.checker_texture()
@@ -30,6 +32,14 @@ def write_model_dir(root):
             f.write("vt %.9g %.9g\n" % tuple(float(x) for x in t))
         for a, b, c in sh.indices + 1:
             f.write(f"f {a}/{a} {b}/{b} {c}/{c}\n")
+    if png_backslash:
+        os.makedirs(os.path.join(d, "textures"), exist_ok=True)
+        with open(os.path.join(d, "default.mtl"), "w") as f:
+            f.write("newmtl default\nKd 1 1 1\nmap_Kd textures\\default.png\n")
+        rgb = np.ascontiguousarray(tex.rgba[:, :, :3])
+        with open(os.path.join(d, "textures", "default.png"), "wb") as f:
+            f.write(_png(tex.width, tex.height, 2, 8, [bytes(r.tobytes()) for r in rgb], filt=lambda y: y % 5, level=6, split=2))
+        return
     with open(os.path.join(d, "default.mtl"), "w") as f:
         f.write("newmtl default\nKd 1 1 1\nmap_Kd default.ppm\n")
     with open(os.path.join(d, "default.ppm"), "wb") as f:
@@ -97,6 +107,14 @@ def test_cpp_scene_script_matches_the_reference_render(tmp_path):
     r = subprocess.run([EXE, str(tmp_path), out3, "160", "120"], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0, r.stderr
     assert open(out3, "rb").read() == my_file, "the multi-context render differs from the single-context one"
+    # N3 once more through the PNG decoder and a backslash map_Kd path (the convention of the reference's sponza.mtl):
+    # the texture as textures/default.png, named "textures\\default.png" in the MTL — the same BMP, byte for byte
+    pdir = tmp_path / "png_models"
+    write_model_dir(str(pdir), png_backslash=True)
+    outp = str(tmp_path / "png.bmp")
+    r = subprocess.run([EXE, str(pdir), outp, "160", "120"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert open(outp, "rb").read() == my_file, "PNG texture behind a backslash path renders differently from the PPM one"
     out2 = str(tmp_path / "whole.bmp")
     r = subprocess.run([EXE, str(tmp_path), out2, "160", "120", "whole"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
