@@ -249,10 +249,13 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* p,
  *   - limit: one RT_TILE x RT_TILE tile x num_samples paths must fit; with 4x4 ambient occlusion and one
  *     light that is num_samples <= 32 (about 1.7 KB of queues per path + 143 MB of fixed spill stacks).
  *     Larger requests fail with RT_ERR_UNSUPPORTED and a message naming the sizes; flags must be 0.
- *   - each GPU holds one such array for the life of the process, shared by every context and call on
- *     that GPU: calls that overlap in time on one GPU (two contexts, or two streams of different
- *     contexts) race on it.  Calls through one context are ordered by the library.
- *   - stream semantics as for rt_render_device. */
+ *   - each GPU holds one such array for the life of the process (every process that loads the library pays
+ *     RT_NOALLOC_SCRATCH_BYTES per GPU it initialises), shared by every context and call on that GPU.  Eager
+ *     calls are ordered by the library, across contexts and streams (one "last user" event per device).
+ *   - under stream capture (pass the capturing stream; NULL is rejected by HIP's capture rules) the call adds
+ *     only kernel and memset nodes and waits on / records no event: order replays of the graph against other
+ *     users of that GPU's scratch yourself — overlapping ones race.
+ *   - stream semantics otherwise as for rt_render_device. */
 #ifndef RT_NOALLOC_SCRATCH_BYTES
 #define RT_NOALLOC_SCRATCH_BYTES (384ull << 20)
 #endif

@@ -693,50 +693,74 @@ RT_FN uint32_t lead_planes_hit(const DScene& S, f3 o, f3 d, const RayGate& rg, H
 // resume at (>= S.num_gates: done).  Nothing is traversed here: the caller queues the roots for k_bvh and calls
 // again, so this walk needs 8 stack entries and no traversal code (the kernel that runs it stays small).
 // One node of that walk: tests gate node i and returns the index of the node to visit next.
-template <bool STATS>
+// DIST (the occlusion walks): only the distance of the closest primitive leaves the walk, so the reference's first-wins
+// rule on equal t cannot matter and the record's primitive / rank / uv are not kept (fewer registers through the walk).
+template <bool STATS, bool DIST = false>
 RT_FN uint32_t gate_step(const DScene& S, f3 o, f3 d, const RayGate& rg, uint32_t i, Hit& best, Stack st, uint32_t& sp, Counters& cnt)
 {
     {
-        const GateNode g = load_gate(S, i);
-        switch (g.kind & G_KIND_MASK) {
+        // the node's first 32 bytes (box / primitive, kind, skip); its last 16 (index, rank, ...) only where they are needed
+        const GateNode* gp = S.gates + i;
+        q4 g0, g1;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (i < S.num_gates_fast) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const __attribute__((address_space(3))) v4f* p = (const __attribute__((address_space(3))) v4f*)(S.gates_fast + i);
+            const v4f a = p[0], b = p[1];
+            g0 = {a.x, a.y, a.z, a.w}; g1 = {b.x, b.y, b.z, b.w};
+        } else
+#endif
+        { g0 = ((const q4*)gp)[0]; g1 = ((const q4*)gp)[1]; }
+        auto tail = [&]() -> q4 {   // {a, rank, prim, item}
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (i < S.num_gates_fast) {
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f c = ((const __attribute__((address_space(3))) v4f*)(S.gates_fast + i))[2];
+                return q4{c.x, c.y, c.z, c.w};
+            }
+#endif
+            return ((const q4*)gp)[2];
+        };
+        const float mn[3] = {g0.x, g0.y, g0.z}, mx[3] = {g1.x, g1.y, g1.z};
+        const uint32_t kindw = f2u(g0.w), skip = f2u(g1.w);
+        auto take = [&](float t, uint32_t prim, uint32_t rank, float u, float v, bool uv) {
+            if (DIST) { if (t < best.t) best.t = t; return; }
+            if (closer(t, rank, best)) { best.t = t; best.prim = prim; best.rank = rank; if (uv) { best.u = u; best.v = v; } }
+        };
+        switch (kindw & G_KIND_MASK) {
         case G_GROUP:
             i++;
             break;
         case G_GATED:
             if (STATS) cnt.gates++;
-            i = ((g.kind & G_SAME_BOX) || (gate_maybe(g.mn, g.mx, rg) && (gate_surely(g.mn, g.mx, o, d, rg) || box_intersects(g.mn, g.mx, o, d)))) ? i + 1 : g.skip;
+            i = ((kindw & G_SAME_BOX) || (gate_maybe(mn, mx, rg) && (gate_surely(mn, mx, o, d, rg) || box_intersects(mn, mx, o, d)))) ? i + 1 : skip;
             break;
         case G_PLANE: {
             float t;
-            if (plane_t(F3(g.mn[0], g.mn[1], g.mn[2]), F3(g.mx[0], g.mx[1], g.mx[2]), o, d, t) && closer(t, g.rank, best)) {
-                best.t = t; best.prim = H_PLANE | g.a; best.rank = g.rank;
-            }
+            if (plane_t(F3(mn[0], mn[1], mn[2]), F3(mx[0], mx[1], mx[2]), o, d, t)) { const q4 c = tail(); take(t, H_PLANE | f2u(c.x), f2u(c.y), 0, 0, false); }
             i++;
             break;
         }
         case G_SPHERE: {
             float t;
-            if (sphere_t(F3(g.mn[0], g.mn[1], g.mn[2]), g.mx[0], o, d, t) && closer(t, g.rank, best)) {
-                best.t = t; best.prim = H_SPHERE | g.a; best.rank = g.rank;
-            }
+            if (sphere_t(F3(mn[0], mn[1], mn[2]), mx[0], o, d, t)) { const q4 c = tail(); take(t, H_SPHERE | f2u(c.x), f2u(c.y), 0, 0, false); }
             i++;
             break;
         }
         case G_TRI: {
-            const q4* T = S.tris + (size_t)g.a * 3;
+            const q4 c = tail();
+            const q4* T = S.tris + (size_t)f2u(c.x) * 3;
             q4 a = T[0], b = T[1], e = T[2];
             if (STATS) cnt.tris++;
             float t, u, v;
-            if (tri_t(xyz(a), xyz(b), xyz(e), o, d, t, u, v) && closer(t, g.rank, best)) {
-                best.t = t; best.prim = H_TRI | g.a; best.u = u; best.v = v; best.rank = g.rank;
-            }
+            if (tri_t(xyz(a), xyz(b), xyz(e), o, d, t, u, v)) take(t, H_TRI | f2u(c.x), f2u(c.y), u, v, true);
             i++;
             break;
         }
         default:   // G_MESH
             if (STATS) cnt.gates++;
-            if ((g.kind & G_SAME_BOX) || (gate_maybe(g.mn, g.mx, rg) && (gate_surely(g.mn, g.mx, o, d, rg) || box_intersects(g.mn, g.mx, o, d))))
-                st.p[(sp++) * st.stride] = g.a;
+            if ((kindw & G_SAME_BOX) || (gate_maybe(mn, mx, rg) && (gate_surely(mn, mx, o, d, rg) || box_intersects(mn, mx, o, d))))
+                st.p[(sp++) * st.stride] = f2u(tail().x);
             i++;
             break;
         }
@@ -795,11 +819,11 @@ RT_FN uint32_t gate_step_q(const DScene& S, const QGate* qg, f3 o, f3 d, const R
 // decides alone before the lanes meet at the exact test — 58.6 / 53.2 / 57.8 / 69.5 ms against 47.2 for this form on
 // config 5: the extra ballots and the second read of the node cost more than the fuller lanes of the exact test gain.)
 
-template <bool STATS>
+template <bool STATS, bool DIST = false>
 RT_FN uint32_t walk_gates(const DScene& S, f3 o, f3 d, const RayGate& rg, uint32_t i, Hit& best, Stack st, uint32_t& sp, Counters& cnt)
 {
     const uint32_t n = S.num_gates;
-    while (i < n && sp < RT_DEFER_ROOTS) i = gate_step<STATS>(S, o, d, rg, i, best, st, sp, cnt);
+    while (i < n && sp < RT_DEFER_ROOTS) i = gate_step<STATS, DIST>(S, o, d, rg, i, best, st, sp, cnt);
     return i;
 }
 

@@ -186,14 +186,15 @@ __global__ void __launch_bounds__(RT_OVF_BLOCK) k_shadow_overflow(DScene S, Rend
 // The hot AO kernel traverses nothing (ao_item): a stack of RT_DEFER_ROOTS mesh roots per lane is all it needs.
 // One lane = one hit and its n*n rays in turn (the AO frame, 48 bytes, is read once per hit; as one item per ray in a
 // blocked stratum-major order the bare item loop — decode, three loads, one store — was 15 of the kernel's 46 ms).
-// Round 3: k_ao runs 5 waves per SIMD (96 VGPRs, no scratch) instead of 4.  Its time follows the waves that fit — with LDS
+// Round 3: k_ao runs 6 waves per SIMD (77 VGPRs, no scratch) instead of 4.  Its time follows the waves that fit — with LDS
 // padding that leaves 4 / 3 / 2 waves per SIMD it takes 39.7 / 47.8 / 65.8 ms on config 3 (T ~ 12 + 108 / waves) — and what
-// had held it at 118 VGPRs was not its own state: the compiler hoisted the 17 fp64 constants of the AO direction
-// (sincos_f64, div_rand_max) out of the stratum loop into 34 vector registers that stayed live through the gate walk.
-// They now arrive through scalar registers (RT_K64, rt_core.hpp): 98 VGPRs, 96 under this cap: 39.6 -> 36.3 ms.
-// At 6 waves (80 VGPRs) 15 dwords spill and the kernel takes 42.7 ms.
+// had held it at 118 VGPRs was not its own state but hoisted constants: (i) the 17 fp64 constants of the AO direction
+// (sincos_f64, div_rand_max), pulled out of the stratum loop into 34 vector registers that stayed live through the gate
+// walk: they now arrive through scalar registers (RT_K64, rt_core.hpp; 118 -> 98 VGPRs); (ii) ~20 registers of small
+// constants hoisted by the machine-level LICM pass, now switched off for this translation unit (Makefile GPU_FLAGS;
+// 94 -> 77).  39.6 ms at 4 waves -> 36.2 at 5 -> 34.2 at 6.
 #ifndef RT_AO_WAVES
-#define RT_AO_WAVES 5
+#define RT_AO_WAVES 6
 #endif
 #define RT_AO_ATTR __attribute__((amdgpu_waves_per_eu(RT_AO_WAVES, RT_AO_WAVES)))
 template <bool STATS>
@@ -249,8 +250,15 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_AO_ATTR k_ao(DScene S, RenderArgs
 #ifndef RT_WALK_CHUNK
 #define RT_WALK_CHUNK 512u            // items per claim, a multiple of 64
 #endif
+// Round 3: 7 waves per SIMD (72 VGPRs, 12 dwords of scratch) instead of 4 — on config 5 the kernel takes 51.2 ms at 4 waves
+// (122 VGPRs, round 2), 45.8 at 5, 42.8 at 6, 41.6 at 7 and 48.1 at 8 (64 VGPRs: 23 dwords of scratch).  What freed the
+// registers: the fp64 constants through scalar registers and no machine LICM (see k_ao above).
+#ifndef RT_AOW_WAVES
+#define RT_AOW_WAVES 7
+#endif
+#define RT_AOW_ATTR __attribute__((amdgpu_waves_per_eu(RT_AOW_WAVES, RT_AOW_WAVES)))
 template <bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK) k_ao_walk(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
+__global__ void __launch_bounds__(RT_BLOCK) RT_AOW_ATTR k_ao_walk(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
 {
     __shared__ uint32_t s_stack[RT_DEFER_ROOTS * RT_BLOCK];
     __shared__ GateNode s_gates[RT_LDS_GATES];
@@ -342,12 +350,16 @@ __global__ void __launch_bounds__(RT_BLOCK) k_ao_walk(DScene S, RenderArgs A, Ba
     flush_counters<STATS>(cnt, B.stats, 2);
 }
 
-// k_ao_walk with the whole gate array resident in LDS as 16-byte compact nodes (QGate, rt_core.hpp) — round 3.
-// k_ao_walk is bound by the texture-address / L1 path (TA busy 77 %): once the lanes of a wave sit on different gate nodes
+// k_ao_walk with the whole gate array resident in LDS as 16-byte compact nodes (QGate, rt_core.hpp) — round 3, built on
+// VERDICT r2's proposal, measured, and NOT the production path (RT_DEBUG bit 128 selects it; the tests keep it correct).
+// k_ao_walk was bound by the texture-address / L1 path (TA busy 77 %): once the lanes of a wave sit on different gate nodes
 // every lane-step is a 48-byte gather of its own cache lines.  Here a step reads 16 bytes from LDS; only a box that the
 // ray may enter (about half of those tested) costs a gather, of the exact 32-byte box that decides it.  One
-// 1024-thread block per CU (16 waves, 4 per SIMD as before) holds 120 KB of nodes + the lanes' root stacks (32 KB) of the
-// CU's 160 KB; scenes with more than RT_QGATE_MAX nodes keep k_ao_walk.  Same items, same results, same queue protocol.
+// 1024-thread block per CU holds 120 KB of nodes + the lanes' root stacks (32 KB) of the CU's 160 KB.
+// Measured on config 5 (profiles/r03a5_*): TA busy 77 -> 49 %, and 47.2 ms against k_ao_walk's 51.2 when both ran 4 waves
+// per SIMD.  But a wave pays the gather whenever ANY of its lanes may enter its box (always, in practice), so the latency
+// per wave-step did not fall, and the block geometry pins this kernel at 16 waves per CU, while the register diet of
+// round 3 lets k_ao_walk run 28: 41.6 ms.  The global walk at 7 waves per SIMD is the production path.
 #define RT_WALKQ_BLOCK 1024
 template <bool STATS>
 __global__ void __launch_bounds__(RT_WALKQ_BLOCK) k_ao_walk_lds(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
@@ -717,7 +729,7 @@ struct GpuBackend {
             // its "group already entered in the overflow list" bits hold for ONE launch (one depth level of one batch)
             hipError_t r = hipMemsetAsync(B.ovf_bits, 0, ovf_bits_bytes, stream);
             if (r != hipSuccess) err = r;
-            if (S.num_qgates && !(S.debug & 64u)) {   // the whole gate array fits LDS: one 1024-thread block per CU
+            if (S.num_qgates && (S.debug & 128u)) {   // experiment switch: the walk over the LDS-resident compact copy (measured slower, see k_ao_walk_lds)
                 timed(RT_K_AO, [&] {
                     if (stats) hipLaunchKernelGGL(k_ao_walk_lds<true>, dim3(256), dim3(RT_WALKQ_BLOCK), 0, stream, S, A, B, d, n);
                     else hipLaunchKernelGGL(k_ao_walk_lds<false>, dim3(256), dim3(RT_WALKQ_BLOCK), 0, stream, S, A, B, d, n);

@@ -551,7 +551,7 @@ RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int dep
             i = (S.debug & 2u) ? S.num_gates : lead_planes_hit(S, o, dir, rg, h);
         }
         for (;;) {
-            if (i < S.num_gates) i = walk_gates<STATS>(S, o, dir, rg, i, h, st, sp, cnt);
+            if (i < S.num_gates) i = walk_gates<STATS, true>(S, o, dir, rg, i, h, st, sp, cnt);
             const bool want = sp > 0;
             const uint32_t item = chunk_append<RT_QCHUNK>(&B.counters[C_BQA + depth], want, qc, B.bq_roots, (uint32_t)REF_NONE, B.bq_cap);
             if (want) {

@@ -253,14 +253,14 @@ def test_config5_full_scale_crop_against_oracle(gpu, port):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("debug", ["8", "24", "88"])
+@pytest.mark.parametrize("debug", ["8", "24", "152"])
 def test_bvh_queue_overflow_falls_back_inline(gpu, debug):
     """RT_DEBUG=8 (read at rt_scene_commit) caps the compacted BVH queue at 3000 items, so most
     mesh rays are redone by the overflow kernels (k_trace_overflow / k_shadow_overflow / k_ao_overflow) and the
     chunked appends run past the capacity: the frame must not change by a bit.  24 = the same with the refilling
-    AO gate walk (RT_DEBUG bit 16: k_ao_walk_lds, the gate nodes as 16-byte copies in LDS), whose overflow list is
-    entered per group of 64 items; 88 = the same with the walk over the full nodes in global memory (bit 64: k_ao_walk,
-    what scenes with more than RT_QGATE_MAX gate nodes run)."""
+    AO gate walk (RT_DEBUG bit 16: k_ao_walk, what scenes with more than 64 gate nodes run), whose overflow list is
+    entered per group of 64 items; 152 = the same with the walk over the 16-byte copies of the gate nodes in LDS
+    (bit 128: k_ao_walk_lds, the measured-and-not-adopted variant of round 3)."""
     import os
     name, world, params = CASES[0]
     p = capi.rt_params.from_buffer_copy(params)
@@ -277,7 +277,7 @@ def test_bvh_queue_overflow_falls_back_inline(gpu, debug):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("debug", ["8", "12", "24", "28", "88", "92"])
+@pytest.mark.parametrize("debug", ["8", "12", "24", "28", "152", "156"])
 def test_overflow_kernels_on_scenes_with_bounces(gpu, port, debug):
     """The overflow kernels (RT_DEBUG bit 8: work queue capped at 3000 items) at EVERY depth level of scenes with
     mirrors / refraction, with the inline shadow kernel (bit 4) and the refilling AO walk (bit 16) switched in:
@@ -299,13 +299,13 @@ def test_overflow_kernels_on_scenes_with_bounces(gpu, port, debug):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("debug", ["16", "80"], ids=["lds_gate_copies", "global_gate_nodes"])
+@pytest.mark.parametrize("debug", ["16", "144"], ids=["global_gate_nodes", "lds_gate_copies"])
 def test_refilling_gate_walk_matches_the_oracle(gpu, port, debug):
     """The AO gate walk of scenes with more than 64 gate nodes, where lanes refill as their walks end, forced on small
-    scenes by RT_DEBUG bit 16 — k_ao_walk_lds (16-byte copies of all gate nodes in LDS, round 3) and, with bit 64,
-    k_ao_walk (full nodes from global memory: scenes with more than RT_QGATE_MAX nodes): against the oracle like every
-    other case, incl. the scene whose rays cross 14 meshes (several queue items per ray).
-    test_other_configs[config5] runs the LDS walk unforced (1200 gate nodes)."""
+    scenes by RT_DEBUG bit 16 — k_ao_walk (full nodes from global memory, the production path) and, with bit 128,
+    k_ao_walk_lds (16-byte copies of all gate nodes in LDS: built in round 3, measured slower, kept selectable): against
+    the oracle like every other case, incl. the scene whose rays cross 14 meshes (several queue items per ray).
+    test_other_configs[config5] runs k_ao_walk unforced (1200 gate nodes)."""
     import os
     os.environ["RT_DEBUG"] = debug
     try:
