@@ -86,7 +86,7 @@ def main():
     ntri = int(flat.arrays["triangles"].shape[0])
     r = Renderer(gpu_index, args.lib)
     r.upload(flat)
-    params = world.params(seed=1)
+    params = world.params(seed=1, max_depth=8) if args.config == 4 else world.params(seed=1)   # BASELINE.json states config 4 at bounce depth 8
     params.tile_rank, params.tile_world = rank, world_size
     params.batch_paths = args.batch_paths
     W, H = args.width, args.height
@@ -293,7 +293,7 @@ def cpu_baseline(world, flat, args):
     else:
         orc, kind = bindings.PortOracle(), "port"
     c = args.cpu_crop or {3: 96, 4: 64}.get(args.config, 24)
-    p = world.params(seed=1)
+    p = world.params(seed=1, max_depth=8) if args.config == 4 else world.params(seed=1)
     p.num_samples = 1
     p.x0, p.x1 = args.width // 2 - c // 2, args.width // 2 - c // 2 + c
     p.y0, p.y1 = args.height // 2 - c // 2, args.height // 2 - c // 2 + c

@@ -238,6 +238,45 @@ RT_FN bool gate_surely(const float* mn, const float* mx, f3 o, f3 d, const RayGa
     return (sx || inx) && (sy || iny) && (sz || inz);
 }
 
+// Both conservative answers from ONE set of slab values (round 3): 0 = the reference's test fails for sure (gate_maybe
+// false), 1 = it passes for sure, 2 = undecided (gate_surely, then the exact test, decide).  The accept costs ~25
+// instructions on top of the reject's 6 fma + min/max where gate_surely recomputes exit planes and a point (~45): the
+// gate walks of config 5 (~100 box gates per ray) and of the reference's own scenes are made of this test.
+// With i_b = 1/d_b (approximate), the values of gate_maybe are, per axis b, en_b = N_b - m_b and ex_b = X_b + m_b up to a
+// rounding rho_b <= e_b/16: N_b / X_b the true entry / exit parameters of the box's slab, m_b = pad*|i_b| + e_b the folded
+// margin, and e_b <= 2.0001*pad*|i_b| because make_gate's E uses the same 2^-18 as cull_pad (DScene::cull_pad; asserted at
+// commit).  Let a = the axis of the smallest ex (f = ex_a) and K_b = 8*pad*|i_b| >= 2*m_b + pad*|i_b| + 4*rho_b.  If, for
+// both axes b != a,  ex_b - f > K_b + K_a  and  f - en_b > K_b + K_a,  then  X_b - X_a > pad*|i_b|  and  X_a - N_b >
+// pad*|i_b|: at the exact parameter X_a at which the ray leaves through face a, its other two coordinates lie inside that
+// face's rectangle by more than pad (>= 20x the rounding of the reference's own t and point, see gate_maybe), so the
+// reference's test of THAT face passes (strict inequalities included) provided its other conditions hold: |d_a| >= 1e-5
+// (all |i_b| < 99 990 is required), t >= 0 (f > K_a gives X_a > m_a > 0) and t < FLT_MAX (f < 1e30).  Boxes that are flat
+// along a, exits near an edge, tiny direction components: class 2.  tests/test_emul.py::test_gate_classification_is_sound
+// checks both implications on random and adversarial rays.
+RT_FN int gate_class(const float* mn, const float* mx, const RayGate& r)
+{
+    const float ax = fmaf(mn[0], r.ix, r.lx), bx = fmaf(mx[0], r.ix, r.hx);
+    const float ay = fmaf(mn[1], r.iy, r.ly), by = fmaf(mx[1], r.iy, r.hy);
+    const float az = fmaf(mn[2], r.iz, r.lz), bz = fmaf(mx[2], r.iz, r.hz);
+    const float enx = fminf(ax, bx), exx = fmaxf(ax, bx);
+    const float eny = fminf(ay, by), exy = fmaxf(ay, by);
+    const float enz = fminf(az, bz), exz = fmaxf(az, bz);
+    const float n = fmaxf(fmaxf(enx, eny), enz);
+    const float f = fminf(fminf(exx, exy), exz);
+    if (!(n <= f && f >= 0.0f)) return 0;
+    const float k8 = 8.0f * r.pad;
+    const float kx = k8 * fabsf(r.ix), ky = k8 * fabsf(r.iy), kz = k8 * fabsf(r.iz);
+    const bool isx = f == exx, isy = !isx && f == exy;   // exactly one axis is the exit face's own
+    const float ks = isx ? kx : (isy ? ky : kz);
+    const float imax = fmaxf(fmaxf(fabsf(r.ix), fabsf(r.iy)), fabsf(r.iz));
+    const bool ok = imax < 99990.0f && f > ks && f < 1e30f;
+    const bool cx = exx - f > kx + ks && f - enx > kx + ks;
+    const bool cy = exy - f > ky + ks && f - eny > ky + ks;
+    const bool cz = exz - f > kz + ks && f - enz > kz + ks;
+    const bool isz = !isx && !isy;
+    return (ok && (isx || cx) && (isy || cy) && (isz || cz)) ? 1 : 2;
+}
+
 // One face of BoundingVolumeBox::intersects (main.cpp:245-296).  For an axis-aligned unit normal
 // the reference's dot products reduce exactly to (c - o[a]) / d[a].
 RT_FN bool box_face(int axis, float c, const float* mn, const float* mx, f3 o, f3 d)
@@ -279,6 +318,14 @@ RT_FN bool box_intersects(const float* mn, const float* mx, f3 o, f3 d)
     }
     return false;
 }
+
+// BoundingVolumeBox::intersects (main.cpp:245-296) as the walks evaluate it: the two conservative answers first, the
+// exact six-face test only for what they leave undecided.  Always the reference's result.  A macro (GNU statement
+// expression), not a function: as a function taking the box by pointer — inlined or not — it made the compiler keep the
+// kernels' by-value DScene argument in scratch memory (560 bytes per lane; k_ao 34 -> 65 ms).
+#define RT_GATE_ENTER(mn_, mx_, o_, d_, rg_) \
+    ({ const int rt_gc_ = gate_class(mn_, mx_, rg_); \
+       rt_gc_ == 1 || (rt_gc_ == 2 && (gate_surely(mn_, mx_, o_, d_, rg_) || box_intersects(mn_, mx_, o_, d_))); })
 
 // Sphere::intersectRay (main.cpp:600-633): far root not divided by 2a
 RT_FN bool sphere_t(f3 centre, float radius_sqr, f3 o, f3 d, float& t)
@@ -733,7 +780,7 @@ RT_FN uint32_t gate_step(const DScene& S, f3 o, f3 d, const RayGate& rg, uint32_
             break;
         case G_GATED:
             if (STATS) cnt.gates++;
-            i = ((kindw & G_SAME_BOX) || (gate_maybe(mn, mx, rg) && (gate_surely(mn, mx, o, d, rg) || box_intersects(mn, mx, o, d)))) ? i + 1 : skip;
+            i = ((kindw & G_SAME_BOX) || RT_GATE_ENTER(mn, mx, o, d, rg)) ? i + 1 : skip;
             break;
         case G_PLANE: {
             float t;
@@ -759,7 +806,7 @@ RT_FN uint32_t gate_step(const DScene& S, f3 o, f3 d, const RayGate& rg, uint32_
         }
         default:   // G_MESH
             if (STATS) cnt.gates++;
-            if ((kindw & G_SAME_BOX) || (gate_maybe(mn, mx, rg) && (gate_surely(mn, mx, o, d, rg) || box_intersects(mn, mx, o, d))))
+            if ((kindw & G_SAME_BOX) || RT_GATE_ENTER(mn, mx, o, d, rg))
                 st.p[(sp++) * st.stride] = f2u(tail().x);
             i++;
             break;
@@ -827,6 +874,82 @@ RT_FN uint32_t walk_gates(const DScene& S, f3 o, f3 d, const RayGate& rg, uint32
     return i;
 }
 
+// The same walk made by a whole WAVE in step (GPU only; round 3).  On the reference's own scenes (a BVHAccel over a dozen
+// shapes of four kinds: configs 1, 2 and 4) the lanes of a wave soon sit on different gate nodes of different kinds, so the
+// per-lane walk above executes the box-gate, sphere, triangle and mesh branches one after the other with a few lanes each
+// (52 % active lanes, 1 775 vector instructions per AO ray against 610 on config 3).  Here ONE node index j runs through the
+// array in preorder and the lanes whose own next node is j (every lane's node index only grows) test it together: the
+// node is wave-uniform, so it comes through scalar loads from the constant address space into scalar registers (no vector
+// registers, no LDS), its kind is a scalar branch, and a wave pays each node of the UNION of its lanes' walks once.  Pays
+// when that union is short (a gate array that fits the kernels' LDS staging limit, RT_LDS_GATES) — with thousands of nodes
+// (config 5) the union is far longer than any one walk.  Every lane visits exactly the nodes of walk_gates, in the same
+// order, with the same tests: same results.  Must be called by all 64 lanes; lanes with nothing to walk pass i >= num_gates.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_CONST_AS __attribute__((address_space(4)))
+template <bool STATS>
+__device__ inline uint32_t walk_gates_wave(const DScene& S, f3 o, f3 d, const RayGate& rg, uint32_t i, float& best_t, Stack st, uint32_t& sp, Counters& cnt)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const RT_CONST_AS v4f* G = (const RT_CONST_AS v4f*)(uintptr_t)S.gates;
+    const RT_CONST_AS v4f* TR = (const RT_CONST_AS v4f*)(uintptr_t)S.tris;
+    const uint32_t n = S.num_gates;
+    for (uint32_t j = S.num_lead_planes; j < n; ++j) {   // wave-uniform
+        const bool mine = i == j && sp < RT_DEFER_ROOTS;
+        if (__builtin_amdgcn_ballot_w64(mine) == 0ull) continue;
+        const v4f g0 = G[3u * j], g1 = G[3u * j + 1u];
+        const float mn[3] = {g0.x, g0.y, g0.z}, mx[3] = {g1.x, g1.y, g1.z};
+        const uint32_t kindw = f2u(g0.w), skip = f2u(g1.w);
+        switch (kindw & G_KIND_MASK) {   // a scalar branch
+        case G_GROUP:
+            if (mine) i = j + 1u;
+            break;
+        case G_GATED:
+            if (mine) {
+                if (STATS) cnt.gates++;
+                i = ((kindw & G_SAME_BOX) || RT_GATE_ENTER(mn, mx, o, d, rg)) ? j + 1u : skip;
+            }
+            break;
+        case G_PLANE:
+            if (mine) {
+                float t;
+                if (plane_t(F3(mn[0], mn[1], mn[2]), F3(mx[0], mx[1], mx[2]), o, d, t) && t < best_t) best_t = t;
+                i = j + 1u;
+            }
+            break;
+        case G_SPHERE:
+            if (mine) {
+                float t;
+                if (sphere_t(F3(mn[0], mn[1], mn[2]), mx[0], o, d, t) && t < best_t) best_t = t;
+                i = j + 1u;
+            }
+            break;
+        case G_TRI: {
+            const uint32_t slot = f2u(G[3u * j + 2u].x);
+            const v4f a = TR[(size_t)slot * 3], b = TR[(size_t)slot * 3 + 1], e = TR[(size_t)slot * 3 + 2];
+            if (mine) {
+                if (STATS) cnt.tris++;
+                float t, u, v;
+                if (tri_t(F3(a.x, a.y, a.z), F3(b.x, b.y, b.z), F3(e.x, e.y, e.z), o, d, t, u, v) && t < best_t) best_t = t;
+                i = j + 1u;
+            }
+            break;
+        }
+        default: {   // G_MESH
+            const uint32_t root = f2u(G[3u * j + 2u].x);
+            if (mine) {
+                if (STATS) cnt.gates++;
+                if ((kindw & G_SAME_BOX) || RT_GATE_ENTER(mn, mx, o, d, rg))
+                    st.p[(sp++) * st.stride] = root;
+                i = j + 1u;
+            }
+            break;
+        }
+        }
+    }
+    return i;
+}
+#endif
+
 // ---- one closest-hit query over world->scene ("one ray") ----------------------------------------
 // MODE 0: closest hit (`for obj in scene: hit |= obj->hit(ray, rec)`, main.cpp:1645-1648, 1390-1393,
 //         1457-1460, 1548-1551) with rec.t starting at tmax.
@@ -870,7 +993,7 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
             break;
         case G_GATED:
             if (STATS) cnt.gates++;
-            i = ((g.kind & G_SAME_BOX) || (gate_maybe(g.mn, g.mx, rg) && (gate_surely(g.mn, g.mx, o, d, rg) || box_intersects(g.mn, g.mx, o, d)))) ? i + 1 : g.skip;
+            i = ((g.kind & G_SAME_BOX) || RT_GATE_ENTER(g.mn, g.mx, o, d, rg)) ? i + 1 : g.skip;
             break;
         case G_PLANE: {
             float t;
@@ -901,7 +1024,7 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
         }
         default: { // G_MESH: gate, then defer its triangle BVH to the shared drain loop
             if (STATS) cnt.gates++;
-            if ((g.kind & G_SAME_BOX) || (gate_maybe(g.mn, g.mx, rg) && (gate_surely(g.mn, g.mx, o, d, rg) || box_intersects(g.mn, g.mx, o, d)))) {
+            if ((g.kind & G_SAME_BOX) || RT_GATE_ENTER(g.mn, g.mx, o, d, rg)) {
                 if (DEFER) {   // the caller queues the roots for k_bvh; one more than an item carries: the caller's overflow path
                     if (sp < RT_DEFER_ROOTS) st.p[sp * st.stride] = g.a;
                     if (++sp > RT_DEFER_ROOTS) { i = n; break; }

@@ -196,17 +196,22 @@ __global__ void __launch_bounds__(RT_OVF_BLOCK) k_shadow_overflow(DScene S, Rend
 #ifndef RT_AO_WAVES
 #define RT_AO_WAVES 6
 #endif
+#ifndef RT_WAVE_WALK_MIN
+#define RT_WAVE_WALK_MIN 12u   // gate nodes behind the lead planes from which k_ao<WAVE> is used (config 3 has 7, the reference's main() scene 30)
+#endif
 #define RT_AO_ATTR __attribute__((amdgpu_waves_per_eu(RT_AO_WAVES, RT_AO_WAVES)))
-template <bool STATS>
+// WAVE: the wave walks the gate array in step, node data through scalar registers (walk_gates_wave): the reference's own
+// scenes (configs 1, 2, 4), where the per-lane walk diverges over node kinds.  No LDS copy of the gates is needed then.
+template <bool STATS, bool WAVE>
 __global__ void __launch_bounds__(RT_BLOCK) RT_AO_ATTR k_ao(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
 {
     __shared__ uint32_t s_stack[RT_DEFER_ROOTS * RT_BLOCK];
-    __shared__ GateNode s_gates[RT_LDS_GATES];
+    __shared__ GateNode s_gates[WAVE ? 1 : RT_LDS_GATES];
 #ifdef RT_AO_LDS_PAD   // experiment: fewer resident waves (issue- or latency-bound?)
     __shared__ uint32_t s_pad[RT_AO_LDS_PAD / 4];
     if (depth == 0x7FFFFFFF) s_pad[threadIdx.x] = 1u;
 #endif
-    stage_gates(S, s_gates);
+    if (!WAVE) stage_gates(S, s_gates);
     const uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
     const uint32_t nslots = depth == 0 ? fixed_n : B.counters[C_QUEUE + depth];
     Stack st{s_stack + threadIdx.x, RT_BLOCK};
@@ -216,7 +221,7 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_AO_ATTR k_ao(DScene S, RenderArgs
     for (uint32_t base = blockIdx.x * RT_BLOCK; base < nslots; base += gridDim.x * RT_BLOCK) {
         const uint32_t slot = base + threadIdx.x;
         bool overflow = false;
-        ao_item<STATS>(S, A, B, depth, slot, slot < nslots, st, cnt, qc, overflow);
+        ao_item<STATS, WAVE>(S, A, B, depth, slot, slot < nslots, st, cnt, qc, overflow);
         if (__builtin_amdgcn_ballot_w64(overflow) != 0ull && (threadIdx.x & 63u) == 0u) {   // queue full: the rays of the wave's 64 slots are redone by k_ao_overflow
             const uint32_t e = atomicAdd(&B.counters[C_AO + depth], 1u);
             if (e < B.ovf_cap) B.ao_ovf[e] = base + (threadIdx.x & ~63u);
@@ -637,6 +642,7 @@ struct GpuBackend {
     std::vector<Span> spans;
     size_t ev_used = 0;
     hipError_t err = hipSuccess;
+    bool wave_walk = false;   // k_ao<WAVE>: the gate walk in step (the reference's own scenes: a few dozen gate nodes of mixed kinds)
     bool walk_refill = false; size_t ovf_bits_bytes = 0;   // k_ao_walk instead of k_ao (scenes with many gate nodes)
 
     size_t ev()
@@ -745,8 +751,13 @@ struct GpuBackend {
         }
         const uint32_t g = grid_for(n, d == 0 ? RT_GRID_AO : RT_MAX_GRID);   // one thread per hit (n*n rays each): many short blocks
         timed(RT_K_AO, [&] {
-            if (stats) hipLaunchKernelGGL(k_ao<true>, dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
-            else hipLaunchKernelGGL(k_ao<false>, dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
+            if (wave_walk) {
+                if (stats) hipLaunchKernelGGL((k_ao<true, true>), dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
+                else hipLaunchKernelGGL((k_ao<false, true>), dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
+            } else {
+                if (stats) hipLaunchKernelGGL((k_ao<true, false>), dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
+                else hipLaunchKernelGGL((k_ao<false, false>), dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
+            }
         });
     }
     void ao_overflow(const RenderArgs& A, int d, uint32_t n)
@@ -1232,6 +1243,8 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
     GpuBackend be{ctx, S, B, stream, (p->flags & RT_FLAG_STATS) != 0, (p->flags & RT_FLAG_TIMING) != 0, levels_alloc};
     // the refilling gate walk pays off when a ray tests many gate nodes (config 5: ~100 of 7500; config 3: 2 of 8)
     be.walk_refill = ((S.num_gates > RT_LDS_GATES && !(S.debug & 32u)) || (S.debug & 16u)) && n2 > 0;
+    // experiment switches: RT_DEBUG bit 256 forces the in-step walk on, bit 512 off
+    be.wave_walk = !be.walk_refill && (((S.num_gates <= RT_LDS_GATES && S.num_gates - S.num_lead_planes >= RT_WAVE_WALK_MIN) && !(S.debug & 512u)) || (S.debug & 256u));
     be.ovf_bits_bytes = 4ull * (B.ovf_cap / 32u + 1u);
     if ((S.debug & 4u) || (uint64_t)P * nl >= (1ull << 31)) be.S.shadow_defer = 0;   // experiment switch / the queue item's 31-bit destination
     if (!capturing) {   // the batch buffers, counters and statistics are the context's: wait for their previous user (any stream)

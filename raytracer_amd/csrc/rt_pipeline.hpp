@@ -527,7 +527,8 @@ RT_FN size_t ao_index(const Batch& B, uint32_t slot, uint32_t k) { return (size_
 // its items') meet in ao_key by minimum.  A wave that finds the queue full sets `overflow`: all rays of its 64
 // slots are redone by ao_overflow_item.
 // GPU: called by all 64 lanes of a wave (`valid` = false for lanes without an item): the queue cursor votes.
-template <bool STATS>
+// WAVE (GPU only): the gate walk is made by the wave in step (walk_gates_wave, rt_core.hpp) instead of lane by lane.
+template <bool STATS, bool WAVE = false>
 RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t slot, bool valid, Stack st,
                    Counters& cnt, QCursor& qc, bool& overflow)
 {
@@ -551,6 +552,10 @@ RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int dep
             i = (S.debug & 2u) ? S.num_gates : lead_planes_hit(S, o, dir, rg, h);
         }
         for (;;) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (WAVE) i = walk_gates_wave<STATS>(S, o, dir, rg, i, h.t, st, sp, cnt);
+            else
+#endif
             if (i < S.num_gates) i = walk_gates<STATS, true>(S, o, dir, rg, i, h, st, sp, cnt);
             const bool want = sp > 0;
             const uint32_t item = chunk_append<RT_QCHUNK>(&B.counters[C_BQA + depth], want, qc, B.bq_roots, (uint32_t)REF_NONE, B.bq_cap);

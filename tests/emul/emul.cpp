@@ -215,12 +215,12 @@ int emul_bvh_dump(const rt_scene_desc* d, uint32_t which, float* out, int cap_no
 
 // Soundness of the conservative gate classification (rt_core.hpp gate_maybe / gate_surely) against the
 // exact reference test, on random and adversarial (edge / corner grazing, tiny direction components,
-// origins on box planes) rays.  out = {tested, maybe_false, surely_true, ambiguous, violations}
+// origins on box planes) rays.  out = {tested, maybe_false, surely_true, ambiguous, violations, accepted by gate_class alone}
 int emul_gate_check(uint32_t n, uint32_t seed, double* out)
 {
     uint64_t s = seed * 0x9E3779B97F4A7C15ull + 12345;
     auto rnd = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (double)((s >> 11) & ((1ull << 53) - 1)) / (double)(1ull << 53); };
-    double cnt[5] = {0, 0, 0, 0, 0};
+    double cnt[6] = {0, 0, 0, 0, 0, 0};
     const float cull_pad = 1.0f / 262144.0f;
     for (uint32_t it = 0; it < n; ++it) {
         float mn[3], mx[3];
@@ -254,13 +254,16 @@ int emul_gate_check(uint32_t n, uint32_t seed, double* out)
         const RayGate rg = make_gate(cull_pad, ext, o, d);
         const bool exact = box_intersects(mn, mx, o, d);
         const bool maybe = gate_maybe(mn, mx, rg);
-        const bool surely = maybe && gate_surely(mn, mx, o, d, rg);
+        const int cls = gate_class(mn, mx, rg);   // the fused form: 0 <=> !maybe, 1 => the exact test passes
+        const bool surely = maybe && (cls == 1 || gate_surely(mn, mx, o, d, rg));
         cnt[0]++;
+        if ((cls == 0) != !maybe || (cls == 1 && !exact) || (bool)RT_GATE_ENTER(mn, mx, o, d, rg) != exact) cnt[4]++;
+        if (cls == 1) cnt[5]++;
         if (!maybe) { cnt[1]++; if (exact) cnt[4]++; }
         else if (surely) { cnt[2]++; if (!exact) cnt[4]++; }
         else cnt[3]++;
     }
-    for (int k = 0; k < 5; ++k) out[k] = cnt[k];
+    for (int k = 0; k < 6; ++k) out[k] = cnt[k];
     return 0;
 }
 

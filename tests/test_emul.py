@@ -113,16 +113,18 @@ def test_more_meshes_on_a_ray_than_deferred_roots(emul, port):
 
 def test_gate_classification_is_sound(emul):
     """gate_maybe == False must imply the reference box test fails, gate_surely == True that it
-    passes (rt_core.hpp); 4 M random + adversarial rays (edges, corners, planes, tiny components)."""
+    passes (rt_core.hpp); 4 M random + adversarial rays (edges, corners, planes, tiny components).
+    Round 3: the fused gate_class (0 <=> gate_maybe false, 1 => the exact test passes) and gate_enter == the exact test."""
     import ctypes as C
     import numpy as np
     lib = emul.lib
     lib.emul_gate_check.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
-    out = np.zeros(5, np.float64)
+    out = np.zeros(6, np.float64)
     for seed in (1, 2):
         assert lib.emul_gate_check(2_000_000, seed, out.ctypes.data) == 0
-        tested, no, yes, amb, bad = out
+        tested, no, yes, amb, bad, fused_yes = out
         assert bad == 0, out
+        assert fused_yes > 0.8 * yes, out                 # the cheap accept decides most of what gate_surely accepts
         assert no > 0.1 * tested and yes > 0.1 * tested   # both shortcuts are exercised
         assert amb < 0.35 * tested                        # the adversarial modes are ~3/8 of the cases
 

@@ -318,6 +318,25 @@ def test_refilling_gate_walk_matches_the_oracle(gpu, port, debug):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("debug", ["256", "512", "264"], ids=["in_step_everywhere", "lane_by_lane_everywhere", "in_step_with_capped_queue"])
+def test_in_step_gate_walk_matches_the_oracle(gpu, port, debug):
+    """k_ao<WAVE> (round 3): the wave walks the gate array in step, node data through scalar registers — the production
+    path of the reference's own scenes (12 or more gate nodes behind the room planes, at most 64 in all).  RT_DEBUG bit
+    256 forces it on every scene (incl. config 3's 7 nodes and the tunnel whose rays cross 14 meshes: more roots than a
+    queue item carries, so lanes wait in mid-walk), bit 512 forces the lane-by-lane walk on the scenes that would take
+    the in-step one, 264 = in step with the work queue capped at 3000 items (overflow kernels)."""
+    import os
+    os.environ["RT_DEBUG"] = debug
+    try:
+        for name, world, params in [c for c in CASES if c[0] in ("default_d2_ao", "default_jitter4_ao_nonsquare", "config3_textured_mesh", "config4_depth8", "matte_directional")]:
+            test_matches_oracle(gpu, port, name, world, params)
+        w = util.mesh_tunnel_scene(96, 72)
+        test_matches_oracle(gpu, port, "mesh_tunnel", w, w.params(seed=5))
+    finally:
+        del os.environ["RT_DEBUG"]
+
+
+@pytest.mark.gpu
 def test_more_meshes_on_a_ray_than_deferred_roots(gpu, port):
     """Rays that pass the gates of 14 meshes: more than the 8 roots a queue item carries, so the walk
     drains inline in mid-walk and queues the rest."""
