@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR(WAVES) k_bvh(DScene 
     bool active = false, exhausted = false;
     uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform
     uint32_t nrays = 0;
-    uint32_t dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // STATS: wave-uniform diagnostics (see ST_DIAG)
+    uint32_t dg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // STATS: wave-uniform diagnostics (see ST_DIAG)
     for (;;) {
         // ---- retire finished rays -------------------------------------------------------------
         if (active && cur == REF_NONE && npend == 0 && (tri >> 28) == 0u) {
@@ -168,7 +168,12 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR(WAVES) k_bvh(DScene 
         if (n_node > n_tri) {
             bool cn = can_node;
             for (int rep = 0;; ++rep) {
-                if (STATS && MODE == BVH_AO) { dg[0]++; dg[1] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(cn)); }
+                if (STATS && MODE == BVH_AO) {
+                    dg[0]++; dg[1] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(cn));
+                    dg[8] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(!active));
+                    dg[9] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(active && cur == REF_NONE));
+                    dg[10] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(active && cur != REF_NONE && !cn));
+                }
                 if (cn) {
                     if (cur & REF_LEAF) {
                         pend[(npend++) * RT_BVH_BLOCK] = cur;   // a leaf that arrived as a root or waited for room (can_node: there is room now)
@@ -207,7 +212,10 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR(WAVES) k_bvh(DScene 
         } else {
             bool ct = can_tri;
             for (int rep = 0;; ++rep) {
-                if (STATS && MODE == BVH_AO) { dg[2]++; dg[3] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ct)); }
+                if (STATS && MODE == BVH_AO) {
+                    dg[2]++; dg[3] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ct));
+                    dg[11] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(active && cur != REF_NONE && (!(cur & REF_LEAF) || npend < RT_PEND)));
+                }
                 if (ct) {
                     if ((tri >> 28) == 0u) {
                         const uint32_t ref = pend[(--npend) * RT_BVH_BLOCK];
@@ -249,6 +257,7 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR(WAVES) k_bvh(DScene 
         for (int off = 32; off > 0; off >>= 1) nrays += __shfl_xor(nrays, off);
         if (lane == 0) atomicAdd(&B.stats[ST_BVHRAYS + cls], (unsigned long long)nrays);
         if (MODE == BVH_AO && lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&B.stats[ST_DIAG + k], (unsigned long long)dg[k]);
+        if (MODE == BVH_AO && lane == 0) for (int k = 0; k < 4; ++k) atomicAdd(&B.stats[ST_DIAG2 + k], (unsigned long long)dg[8 + k]);
     }
 }
 

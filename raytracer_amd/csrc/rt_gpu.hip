@@ -1285,6 +1285,10 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
             std::fprintf(stderr, "[k_bvh<AO>] node steps %llu (%.1f lanes each), triangle steps %llu (%.1f lanes each), votes %llu (%.1f active lanes), refills %llu (%.1f rays each)\n",
                          h[ST_DIAG], (double)h[ST_DIAG + 1] / std::max(1ull, h[ST_DIAG]), h[ST_DIAG + 2], (double)h[ST_DIAG + 3] / std::max(1ull, h[ST_DIAG + 2]),
                          h[ST_DIAG + 4], (double)h[ST_DIAG + 5] / std::max(1ull, h[ST_DIAG + 4]), h[ST_DIAG + 6], (double)h[ST_DIAG + 7] / std::max(1ull, h[ST_DIAG + 6]));
+        if (getenv("RT_BVH_DIAG") && h[ST_DIAG + 0] + h[ST_DIAG + 2] > 0)
+            std::fprintf(stderr, "[k_bvh<AO>] per node step: %.1f lanes without a ray, %.1f with parked triangles only, %.1f waiting for room to park a leaf; per triangle step: %.1f lanes could take a node step\n",
+                         (double)h[ST_DIAG2] / std::max(1ull, h[ST_DIAG]), (double)h[ST_DIAG2 + 1] / std::max(1ull, h[ST_DIAG]), (double)h[ST_DIAG2 + 2] / std::max(1ull, h[ST_DIAG]),
+                         (double)h[ST_DIAG2 + 3] / std::max(1ull, h[ST_DIAG + 2]));
         for (int k = 0; k < 3; ++k) { stats->nodes[k] = h[ST_NODES + k]; stats->tris[k] = h[ST_TRIS + k]; stats->gates[k] = h[ST_GATES + k]; stats->bvh_rays[k] = h[ST_BVHRAYS + k]; }
         float ms = 0.0f;
         HIPCHECK(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));

@@ -29,7 +29,8 @@ enum { C_QUEUE = 0, C_AO = 64, C_SH = 128, C_BQ = 192, C_BQA = 256, C_BQ_NEXT = 
 enum { ST_SHADOW = 0, ST_AO = 1, ST_BOUNCE = 2, ST_NODES = 3, ST_TRIS = 6, ST_GATES = 9, ST_BVHRAYS = 12,
        ST_DIAG = 15 /* k_bvh<AO> lane-packing diagnostics of the counting variant: node steps, lanes in them, triangle steps, lanes in them, votes, active lanes at votes, refills, lanes refilled */,
        ST_SKIPPED = 23 /* closest-hit queries the reference traces and this path proves unnecessary (prep_item) */,
-       ST_TOTAL = 24 }; // u64
+       ST_DIAG2 = 24 /* more of the same, summed over node steps: lanes without a ray, lanes whose ray has only parked triangles left, lanes waiting with a leaf for room in the parked list; summed over triangle steps: lanes that could take a node step */,
+       ST_TOTAL = 28 }; // u64
 #define RT_MAX_LEVELS 62
 
 struct Batch {
