@@ -110,6 +110,9 @@ def main():
         # on torch's current stream: ordered behind the gather that filled `t` (PendingGather.finish waited for it)
         if not t.is_cuda:
             t = t.to(dev)
+        if world_size == 1:   # --force-collective rehearsal: with tile_world == 1 the library writes a row-major frame, not a tile slab (include/rt_amd.h)
+            frame.view(-1).copy_(t.view(-1)[:frame.numel()])
+            return
         r.unpack_tiles(t.data_ptr(), params, src, world_size, frame.data_ptr(), torch.cuda.current_stream().cuda_stream)
 
     def flush():

@@ -199,11 +199,14 @@ __global__ void __launch_bounds__(RT_OVF_BLOCK) k_shadow_overflow(DScene S, Rend
 #ifndef RT_WAVE_WALK_MIN
 #define RT_WAVE_WALK_MIN 12u   // gate nodes behind the lead planes from which k_ao<WAVE> is used (config 3 has 7, the reference's main() scene 30)
 #endif
-#define RT_AO_ATTR __attribute__((amdgpu_waves_per_eu(RT_AO_WAVES, RT_AO_WAVES)))
+#ifndef RT_AO_WAVES_INSTEP
+#define RT_AO_WAVES_INSTEP 7   // k_ao<WAVE>: 71 VGPRs without scratch (the per-lane walk needs 32 bytes of scratch at 7 waves: 33.9 -> 36.3 ms); config 4 k_ao 24.2 -> 23.7 ms at half size
+#endif
+#define RT_AO_ATTR(W) __attribute__((amdgpu_waves_per_eu(W, W)))
 // WAVE: the wave walks the gate array in step, node data through scalar registers (walk_gates_wave): the reference's own
 // scenes (configs 1, 2, 4), where the per-lane walk diverges over node kinds.  No LDS copy of the gates is needed then.
-template <bool STATS, bool WAVE>
-__global__ void __launch_bounds__(RT_BLOCK) RT_AO_ATTR k_ao(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
+template <bool STATS, bool WAVE, int WAVES>
+__global__ void __launch_bounds__(RT_BLOCK) RT_AO_ATTR(WAVES) k_ao(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
 {
     __shared__ uint32_t s_stack[RT_DEFER_ROOTS * RT_BLOCK];
     __shared__ GateNode s_gates[WAVE ? 1 : RT_LDS_GATES];
@@ -752,11 +755,11 @@ struct GpuBackend {
         const uint32_t g = grid_for(n, d == 0 ? RT_GRID_AO : RT_MAX_GRID);   // one thread per hit (n*n rays each): many short blocks
         timed(RT_K_AO, [&] {
             if (wave_walk) {
-                if (stats) hipLaunchKernelGGL((k_ao<true, true>), dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
-                else hipLaunchKernelGGL((k_ao<false, true>), dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
+                if (stats) hipLaunchKernelGGL((k_ao<true, true, RT_AO_WAVES_INSTEP>), dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
+                else hipLaunchKernelGGL((k_ao<false, true, RT_AO_WAVES_INSTEP>), dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
             } else {
-                if (stats) hipLaunchKernelGGL((k_ao<true, false>), dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
-                else hipLaunchKernelGGL((k_ao<false, false>), dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
+                if (stats) hipLaunchKernelGGL((k_ao<true, false, RT_AO_WAVES>), dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
+                else hipLaunchKernelGGL((k_ao<false, false, RT_AO_WAVES>), dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
             }
         });
     }
