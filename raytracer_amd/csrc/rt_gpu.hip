@@ -269,8 +269,9 @@ template <bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK) RT_AOW_ATTR k_ao_walk(DScene S, RenderArgs A, Batch B, int depth, uint32_t fixed_n)
 {
     __shared__ uint32_t s_stack[RT_DEFER_ROOTS * RT_BLOCK];
-    __shared__ GateNode s_gates[RT_LDS_GATES];
-    stage_gates(S, s_gates);
+    // no LDS copy of the first gate nodes here: with thousands of nodes the lanes sit on nodes far beyond the first 64, and
+    // the two-source node fetch (LDS | global, both executed by a wave whose lanes differ) was a tenth of a step's instructions
+    S.gates_fast = nullptr; S.num_gates_fast = 0;
     const uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
     const uint32_t nslots = depth == 0 ? fixed_n : B.counters[C_QUEUE + depth];
     const uint32_t n = nslots * n2;
