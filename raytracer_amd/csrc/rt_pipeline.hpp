@@ -339,10 +339,12 @@ RT_FN bool prep_body(const DScene& S, const RenderArgs& A, const Batch& B, int d
     PathPix px = path_of(A, p);
     p_out = p;
     if (depth == 0 && !px.valid) return false;
+    // the records the path index addresses are requested together, before the first test (see shade_item)
     q4 h4 = B.hit[p];
+    q4 o4 = B.ray_o[depth & 1][p], d4 = B.ray_d[depth & 1][p];
+    uint32_t ps = B.pstate[p];
     Hit h; h.t = h4.x; h.prim = f2u(h4.y); h.u = h4.z; h.v = h4.w;
     size_t li = (size_t)depth * B.P + p;
-    q4 o4 = B.ray_o[depth & 1][p], d4 = B.ray_d[depth & 1][p];
     f3 o = xyz(o4), d = xyz(d4);
     if (h.prim == H_MISS) {
         B.lvl_kind[li] = LK_NONE;
@@ -365,7 +367,6 @@ RT_FN bool prep_body(const DScene& S, const RenderArgs& A, const Batch& B, int d
     f3 P = o + d * h.t;   // sr.ray(sr.t) = o + t*d
 
     // ambient term: every class but Refraction evaluates world->ambient->L(sr)
-    uint32_t ps = B.pstate[p];
     uint32_t slot = 0xFFFFFFFFu;
     if (M.kind != RT_MAT_REFRACTION && S.ambient.occlusion_samples > 0) {
         uint32_t a = ps & 0xFFu;
@@ -595,12 +596,12 @@ RT_FN void ao_overflow_item(const DScene& S, const RenderArgs& A, const Batch& B
 }
 
 // world->ambient->L(sr): Light::L, or Ambient::L's reduction of the n*n distances in x,y order
-RT_FN f3 ambient_L(const DScene& S, const Batch& B, uint32_t p)
+// `slot` = B.ao_slot[p] (0xFFFFFFFF: the path shot no AO rays; not read when the ambient light has no occlusion samples)
+RT_FN f3 ambient_L(const DScene& S, const Batch& B, uint32_t slot)
 {
     const rt_ambient& A = S.ambient;
     f3 base = F3(A.colour[0], A.colour[1], A.colour[2]) * A.radiance;
     if (A.occlusion_samples <= 0) return base;
-    uint32_t slot = B.ao_slot[p];
     if (slot == 0xFFFFFFFFu) return base;
     unsigned n = (unsigned)A.occlusion_samples;
     float dist = A.occlusion_dist;
@@ -615,21 +616,28 @@ RT_FN void shade_item(const DScene& S, const RenderArgs& A, const Batch& B, int 
 {
     uint32_t p = item_path(A, B, depth, idx);
     if (depth == 0 && !path_of(A, p).valid) return;
+    const uint32_t nl = S.num_lights;
+    // Everything the path index alone addresses is requested before the first test (round 3): this kernel is a chain of
+    // dependent loads (hit -> normal -> material -> ray -> AO slot -> 16 distances -> texture -> texel: 91 % of its wave
+    // cycles were waits), and a load behind an early return cannot be started before the branch is decided.  Stale
+    // records of paths that missed are read (in range) and not used.
     q4 h4 = B.hit[p];
+    q4 n4 = B.nrm[p];
+    q4 o4 = B.ray_o[depth & 1][p], d4 = B.ray_d[depth & 1][p];
+    const uint32_t slot = S.ambient.occlusion_samples > 0 ? B.ao_slot[p] : 0xFFFFFFFFu;
+    const float shadow0 = nl > 0 ? B.sh_res[(size_t)p * nl] : 1.0f;
     if (f2u(h4.y) == H_MISS) return;
     size_t li = (size_t)depth * B.P + p;
-    q4 n4 = B.nrm[p];
     f3 N = xyz(n4);
     const DMaterial M = S.materials[f2u(n4.w)];
+    const f3 amb = ambient_L(S, B, slot);   // a Refraction surface has no slot: no loads
     if (M.kind == RT_MAT_REFRACTION) return;   // Refraction::shade = clamp(child): nothing local
-    q4 o4 = B.ray_o[depth & 1][p], d4 = B.ray_d[depth & 1][p];
     f3 o = xyz(o4), d = xyz(d4);
     f3 P = o + d * h4.x;
     f3 colour = F3(M.colour[0], M.colour[1], M.colour[2]);
-    const uint32_t nl = S.num_lights;
     q4 out;
     if (M.kind == RT_MAT_MATTE) {   // main.cpp:1143-1165
-        f3 L = (colour * M.ka) * ambient_L(S, B, p);
+        f3 L = (colour * M.ka) * amb;
         for (uint32_t l = 0; l < nl; ++l) {
             f3 wi = light_direction(S.lights[l], P);
             float nDotWi = dot(N, wi);
@@ -638,12 +646,12 @@ RT_FN void shade_item(const DScene& S, const RenderArgs& A, const Batch& B, int 
         out = {L.x, L.y, L.z, 0.0f};
     } else if (M.kind == RT_MAT_SPECULAR) {   // main.cpp:1215-1244
         f3 wo = normalize(-d);
-        f3 L = (colour * M.ka) * ambient_L(S, B, p);
+        f3 L = (colour * M.ka) * amb;
         for (uint32_t l = 0; l < nl; ++l) {
             f3 wi = normalize(light_direction(S.lights[l], P));
             float nDotWi = dot(N, wi);
             if (nDotWi > 0.0f) {
-                float shadow = B.sh_res[p * nl + l];
+                float shadow = l == 0 ? shadow0 : B.sh_res[p * nl + l];
                 L = L + ((colour * M.kd) * 0.318309886183790671537767526745028724f) * light_L(S.lights[l]) * nDotWi * shadow;
                 float sp = specular_fn(M.ks, M.spec_exp, N, wo, wi);
                 L = L + F3(sp, sp, sp) * shadow;
@@ -654,12 +662,12 @@ RT_FN void shade_item(const DScene& S, const RenderArgs& A, const Batch& B, int 
     } else if (M.kind == RT_MAT_TEXTURED) {   // main.cpp:1269-1299
         f3 tex = texture_colour(S, M.texture, h4.z, h4.w);
         f3 wo = normalize(-d);
-        f3 L = (F3(1.0f, 1.0f, 1.0f) * M.ka) * ambient_L(S, B, p) * tex;
+        f3 L = (F3(1.0f, 1.0f, 1.0f) * M.ka) * amb * tex;
         for (uint32_t l = 0; l < nl; ++l) {
             f3 wi = normalize(light_direction(S.lights[l], P));
             float nDotWi = dot(N, wi);
             if (nDotWi > 0.0f) {
-                float shadow = B.sh_res[p * nl + l];
+                float shadow = l == 0 ? shadow0 : B.sh_res[p * nl + l];
                 float ldist = length(light_source(S.lights[l], P) - P);
                 float att = A.light_atten / (ldist * ldist);
                 L = L + tex * light_L(S.lights[l]) * nDotWi * att * shadow;
@@ -671,7 +679,7 @@ RT_FN void shade_item(const DScene& S, const RenderArgs& A, const Batch& B, int 
         out = {L.x, L.y, L.z, 0.0f};
     } else {   // MIRROR (main.cpp:1487-1511): store the ambient term and the per-light phong terms
         f3 wo = normalize(-d);
-        f3 L = (colour * M.ka) * ambient_L(S, B, p);
+        f3 L = (colour * M.ka) * amb;
         out = {L.x, L.y, L.z, 0.0f};
         for (uint32_t l = 0; l < nl; ++l) {
             f3 wi = normalize(light_direction(S.lights[l], P));
