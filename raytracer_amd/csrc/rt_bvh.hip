@@ -23,16 +23,25 @@ using namespace rt;
 #define RT_BVH_CHUNK 512
 #endif
 #ifndef RT_REFILL_IDLE
-#define RT_REFILL_IDLE 40    // refill once this many lanes hold no ray
+#define RT_REFILL_IDLE 20    // refill once this many lanes hold no ray (40 until the vote below was re-weighted)
 #endif
 #ifndef RT_PEND
 #define RT_PEND 2            // parked leaves per lane
 #endif
 #ifndef RT_NODE_REPS
-#define RT_NODE_REPS 4       // steps of one kind per vote (see the vote below)
+#define RT_NODE_REPS 3       // steps of one kind per vote (see the vote below)
 #endif
 #ifndef RT_TRI_REPS
 #define RT_TRI_REPS 6
+#endif
+#ifndef RT_VOTE_NUM
+// A node step wins the vote when n_node * RT_VOTE_DEN > n_tri * RT_VOTE_NUM.  Round 3: 3 : 1 instead of 1 : 1 — a triangle step
+// costs half a node step and is what frees lanes (a ray whose stack is empty only waits for its parked triangles: 9.6 lanes per
+// node step, RT_BVH_DIAG), so it pays to take it as soon as a third as many lanes want it; with that, refilling at 20 idle
+// lanes instead of 40 and 3 repeated node steps instead of 4 became the best of their sweeps: k_bvh<AO> 97.7 -> 92.1 ms on
+// config 3 (2 : 1 ... 3 : 1, 16 ... 24 idle lanes, 2 ... 4 steps all within 0.5 ms), 21.5 -> 21.05 ms on config 5.
+#define RT_VOTE_NUM 3
+#define RT_VOTE_DEN 1
 #endif
 #ifndef RT_REP_NUM
 #define RT_REP_NUM 1         // repeat while RT_REP_NUM/RT_REP_DEN of the voters are ready again
@@ -165,7 +174,7 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR(WAVES) k_bvh(DScene 
         // The winner of the vote is repeated (up to RT_*_REPS steps) while RT_REP_NUM/RT_REP_DEN of its voters
         // are ready again: the retire / refill / vote code above is a third of an iteration.
         if (STATS && MODE == BVH_AO) { dg[4]++; dg[5] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(active)); }
-        if (n_node > n_tri) {
+        if (n_node * RT_VOTE_DEN > n_tri * RT_VOTE_NUM) {
             bool cn = can_node;
             for (int rep = 0;; ++rep) {
                 if (STATS && MODE == BVH_AO) {
