@@ -26,7 +26,7 @@ using namespace rt;
 #define RT_REFILL_IDLE 20    // refill once this many lanes hold no ray (40 until the vote below was re-weighted)
 #endif
 #ifndef RT_PEND
-#define RT_PEND 2            // parked leaves per lane
+#define RT_PEND 1            // parked leaves per lane: 1 = in a register (round 3; 2 in LDS until the vote below was re-weighted: 92.0 -> 89.9 ms)
 #endif
 #ifndef RT_NODE_REPS
 #define RT_NODE_REPS 3       // steps of one kind per vote (see the vote below)
@@ -41,6 +41,8 @@ using namespace rt;
 // lanes instead of 40 and 3 repeated node steps instead of 4 became the best of their sweeps: k_bvh<AO> 97.7 -> 92.1 ms on
 // config 3 (2 : 1 ... 3 : 1, 16 ... 24 idle lanes, 2 ... 4 steps all within 0.5 ms), 21.5 -> 21.05 ms on config 5.
 #define RT_VOTE_NUM 3
+#endif
+#ifndef RT_VOTE_DEN
 #define RT_VOTE_DEN 1
 #endif
 #ifndef RT_REP_NUM
@@ -68,7 +70,9 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR(WAVES) k_bvh(DScene 
     // a pop discard an entry whose box has fallen behind the closest hit found since it was pushed without
     // fetching the node (18 % of the node fetches of an AO ray otherwise).
     __shared__ uint2 s_stack[RT_LDS_STACK * RT_BVH_BLOCK];
+#if RT_PEND > 1
     __shared__ uint32_t s_pend[RT_PEND * RT_BVH_BLOCK];
+#endif
 #ifdef RT_BVH_LDS_PAD   // experiment: fewer resident waves (round 3: is the kernel bound by issue or by latency? see DESIGN.md 4)
     __shared__ uint32_t s_pad[RT_BVH_LDS_PAD / 4];
     if (counter == 0x7FFFFFFF) s_pad[threadIdx.x] = 1u;
@@ -97,13 +101,29 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR(WAVES) k_bvh(DScene 
     // the queue counter (the launches of the deeper levels of a small frame hold a few hundred rays for 8192 waves)
     if ((uint64_t)(blockIdx.x * (RT_BVH_BLOCK / 64) + (threadIdx.x >> 6)) * 64u >= n) return;
     uint32_t* next = &B.counters[next_counter];
-    uint32_t* pend = s_pend + threadIdx.x;
     Counters cnt{0, 0, 0, 0};
     const uint32_t lane = threadIdx.x & 63u;
     f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
     RayCull4 rc = {};
     Hit best = {};
-    uint32_t sp = 0, cur = REF_NONE, dst = 0, npend = 0;
+    uint32_t sp = 0, cur = REF_NONE, dst = 0;
+    // the parked leaves of the lane
+#if RT_PEND > 1
+    uint32_t npend = 0;
+    uint32_t* pend = s_pend + threadIdx.x;
+    #define PEND_ANY() (npend > 0)
+    #define PEND_ROOM() (npend < RT_PEND)
+    #define PEND_PUSH(x) (pend[(npend++) * RT_BVH_BLOCK] = (x))
+    #define PEND_POP() (pend[(--npend) * RT_BVH_BLOCK])
+    #define PEND_CLEAR() (npend = 0)
+#else
+    uint32_t pend0 = REF_NONE;
+    #define PEND_ANY() (pend0 != REF_NONE)
+    #define PEND_ROOM() (pend0 == REF_NONE)
+    #define PEND_PUSH(x) (pend0 = (x))
+    #define PEND_POP() (pend0)
+    #define PEND_CLEAR() (pend0 = REF_NONE)
+#endif
     uint32_t tri = 0;   // triangles of the leaf being tested: next slot (bits 0..27) | triangles left (bits 28..31)
     bool active = false, exhausted = false;
     uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform
@@ -111,7 +131,7 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR(WAVES) k_bvh(DScene 
     uint32_t dg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // STATS: wave-uniform diagnostics (see ST_DIAG)
     for (;;) {
         // ---- retire finished rays -------------------------------------------------------------
-        if (active && cur == REF_NONE && npend == 0 && (tri >> 28) == 0u) {
+        if (active && cur == REF_NONE && !PEND_ANY() && (tri >> 28) == 0u) {
             if (MODE == BVH_AO) key_min(&B.ao_key[dst], t_key(best.t));   // the ray's other items and k_ao's own hit meet here
             else if (MODE == BVH_SHADOW) { if (best.prim != H_MISS) B.sh_res[dst] = 0.0f; }   // k_shadow_defer stored what holds otherwise
             else { const q4 r = {best.t, u2f(best.prim), best.u, best.v}; B.hit[dst] = r; }
@@ -148,7 +168,7 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR(WAVES) k_bvh(DScene 
                     best.t = a.w; best.prim = H_MISS; best.rank = 0; best.u = 0; best.v = 0;
                     if (!AO) { const q4 c = B.bq_c[idx]; best.prim = f2u(c.x); best.rank = f2u(c.y); best.u = c.z; best.v = c.w; }
                     rc = make_cull4(S, o, d);
-                    sp = 0; npend = 0; tri = 0;
+                    sp = 0; PEND_CLEAR(); tri = 0;
                     if (root0 != REF_NONE) {
                         push(sp, root0, -INFINITY);
                         if (multi)   // rare: one Mesh is the rule; a list shorter than RT_DEFER_ROOTS ends with REF_NONE
@@ -163,8 +183,8 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR(WAVES) k_bvh(DScene 
             }
         }
         // ---- vote for the kind of step ------------------------------------------------------------
-        const bool can_node = active && cur != REF_NONE && (!(cur & REF_LEAF) || npend < RT_PEND);
-        const bool can_tri = active && ((tri >> 28) != 0u || npend > 0);
+        const bool can_node = active && cur != REF_NONE && (!(cur & REF_LEAF) || PEND_ROOM());
+        const bool can_tri = active && ((tri >> 28) != 0u || PEND_ANY());
         const uint32_t n_node = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(can_node));
         const uint32_t n_tri = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(can_tri));
         if (n_node == 0 && n_tri == 0) {
@@ -185,7 +205,7 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR(WAVES) k_bvh(DScene 
                 }
                 if (cn) {
                     if (cur & REF_LEAF) {
-                        pend[(npend++) * RT_BVH_BLOCK] = cur;   // a leaf that arrived as a root or waited for room (can_node: there is room now)
+                        PEND_PUSH(cur);   // a leaf that arrived as a root or waited for room (can_node: there is room now)
                     } else {
                         float t4[4];
                         uint32_t r4[4];
@@ -209,13 +229,13 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR(WAVES) k_bvh(DScene 
                     while (x == REF_NONE && sp > 0) {
                         const uint2 y = pop(sp);
                         if (u2f(y.y) > best.t) continue;
-                        if ((y.x & REF_LEAF) && npend < RT_PEND) pend[(npend++) * RT_BVH_BLOCK] = y.x;
+                        if ((y.x & REF_LEAF) && PEND_ROOM()) PEND_PUSH(y.x);
                         else x = y.x;
                     }
                     cur = x;
                 }
                 if (rep == RT_NODE_REPS - 1) break;
-                cn = active && cur != REF_NONE && (!(cur & REF_LEAF) || npend < RT_PEND);
+                cn = active && cur != REF_NONE && (!(cur & REF_LEAF) || PEND_ROOM());
                 if ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(cn)) * RT_REP_DEN < n_node * RT_REP_NUM) break;
             }
         } else {
@@ -223,11 +243,14 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR(WAVES) k_bvh(DScene 
             for (int rep = 0;; ++rep) {
                 if (STATS && MODE == BVH_AO) {
                     dg[2]++; dg[3] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ct));
-                    dg[11] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(active && cur != REF_NONE && (!(cur & REF_LEAF) || npend < RT_PEND)));
+                    dg[11] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(active && cur != REF_NONE && (!(cur & REF_LEAF) || PEND_ROOM())));
                 }
                 if (ct) {
                     if ((tri >> 28) == 0u) {
-                        const uint32_t ref = pend[(--npend) * RT_BVH_BLOCK];
+                        const uint32_t ref = PEND_POP();
+#if RT_PEND == 1
+                        pend0 = REF_NONE;
+#endif
                         tri = (ref & 0x7FFFFFFFu) + 0x10000000u;   // leaf reference: count-1 in bits 28..30 -> count in bits 28..31
                     }
                     const uint32_t tri_next = tri & 0x0FFFFFFFu;
@@ -247,19 +270,24 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR(WAVES) k_bvh(DScene 
                     const bool ok = !(det < 0.000001f) && !(u < 0 || u > 1) && !(v < 0 || u + v > 1);
                     const uint32_t rank = f2u(e.w);
                     if (MODE == BVH_SHADOW) {   // all-opaque meshes: the first triangle before the light decides, the ray is done
-                        if (ok && t < best.t) { best.prim = H_TRI; sp = 0; npend = 0; tri = (tri & 0x0FFFFFFFu) | 0x10000000u; cur = REF_NONE; }
+                        if (ok && t < best.t) { best.prim = H_TRI; sp = 0; PEND_CLEAR(); tri = (tri & 0x0FFFFFFFu) | 0x10000000u; cur = REF_NONE; }
                     } else if (MODE == BVH_AO) {   // only the distance leaves this kernel: the reference's first-wins rule on equal t cannot change it
                         if (ok && t < best.t) best.t = t;
                     } else if (ok && closer(t, rank, best)) { best.t = t; best.prim = H_TRI | tri_next; best.u = u; best.v = v; best.rank = rank; }
                     tri += 0xF0000001u;   // next slot, one triangle fewer
                 }
                 if (rep == RT_TRI_REPS - 1) break;
-                ct = active && ((tri >> 28) != 0u || npend > 0);
+                ct = active && ((tri >> 28) != 0u || PEND_ANY());
                 if ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ct)) * RT_REP_DEN < n_tri * RT_REP_NUM) break;
             }
         }
     }
     #undef spill
+    #undef PEND_ANY
+    #undef PEND_ROOM
+    #undef PEND_PUSH
+    #undef PEND_POP
+    #undef PEND_CLEAR
     constexpr int cls = MODE == BVH_AO ? 2 : MODE == BVH_SHADOW ? 1 : 0;
     flush_counters<STATS>(cnt, B.stats, cls);
     if (STATS) {
