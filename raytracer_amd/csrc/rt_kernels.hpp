@@ -16,7 +16,9 @@
 // six blocks fit a CU's 160 KB — with the register diet of rt_bvh.hip / RayCull4 (80 VGPRs, no scratch) the kernel runs
 // 6 waves per SIMD instead of 5: k_bvh<AO> 102.9 -> 98.5 ms on config 3.  Measured around it: 14 entries at 5 waves
 // 102.9, 12 at 5 waves 104.1, 10 at 6 waves 103.6, 10 at 7 waves (3 dwords of scratch) 98.5, 16 at 4 waves 116.7.
-#define RT_LDS_STACK 12
+// Later in round 3 the lane's parked leaf moved from LDS into a register (rt_bvh.hip), which made room for a 13th entry
+// (26 KB per block, six blocks per CU as before): 89.5 -> 88.8 ms.
+#define RT_LDS_STACK 13
 #endif
 #ifndef RT_BVH_BLOCK
 #define RT_BVH_BLOCK RT_BLOCK   // threads per block and blocks of the persistent kernel (swept 64-512 / 1024-8192: no effect)
