@@ -742,7 +742,13 @@ RT_FN uint32_t lead_planes_hit(const DScene& S, f3 o, f3 d, const RayGate& rg, H
 // One node of that walk: tests gate node i and returns the index of the node to visit next.
 // DIST (the occlusion walks): only the distance of the closest primitive leaves the walk, so the reference's first-wins
 // rule on equal t cannot matter and the record's primitive / rank / uv are not kept (fewer registers through the walk).
-template <bool STATS, bool DIST = false>
+// (Measured and dropped, round 3: leaving a box gate that neither conservative answer decides open until the end of
+// k_ao_walk's round, so that gate_surely and the exact test run once for all such lanes instead of in every step in which
+// one lane needs them: 38.9 -> 39.2 ms on config 5.)
+// FAST = false: the kernel has no LDS copy of the first gate nodes (k_ao_walk) — a template flag, not DScene::num_gates_fast
+// = 0 written by the kernel: a kernel that writes its by-value DScene makes the compiler keep a private copy of it, and
+// whether that copy is split into registers or left in scratch memory (600 bytes per lane) has flipped with unrelated edits.
+template <bool STATS, bool DIST = false, bool FAST = true>
 RT_FN uint32_t gate_step(const DScene& S, f3 o, f3 d, const RayGate& rg, uint32_t i, Hit& best, Stack st, uint32_t& sp, Counters& cnt)
 {
     {
@@ -750,7 +756,7 @@ RT_FN uint32_t gate_step(const DScene& S, f3 o, f3 d, const RayGate& rg, uint32_
         const GateNode* gp = S.gates + i;
         q4 g0, g1;
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (i < S.num_gates_fast) {
+        if (FAST && i < S.num_gates_fast) {
             typedef float v4f __attribute__((ext_vector_type(4)));
             const __attribute__((address_space(3))) v4f* p = (const __attribute__((address_space(3))) v4f*)(S.gates_fast + i);
             const v4f a = p[0], b = p[1];
@@ -760,7 +766,7 @@ RT_FN uint32_t gate_step(const DScene& S, f3 o, f3 d, const RayGate& rg, uint32_
         { g0 = ((const q4*)gp)[0]; g1 = ((const q4*)gp)[1]; }
         auto tail = [&]() -> q4 {   // {a, rank, prim, item}
 #if defined(__HIP_DEVICE_COMPILE__)
-            if (i < S.num_gates_fast) {
+            if (FAST && i < S.num_gates_fast) {
                 typedef float v4f __attribute__((ext_vector_type(4)));
                 const v4f c = ((const __attribute__((address_space(3))) v4f*)(S.gates_fast + i))[2];
                 return q4{c.x, c.y, c.z, c.w};

@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_AOW_ATTR k_ao_walk(DScene S, Rend
     __shared__ uint32_t s_stack[RT_DEFER_ROOTS * RT_BLOCK];
     // no LDS copy of the first gate nodes here: with thousands of nodes the lanes sit on nodes far beyond the first 64, and
     // the two-source node fetch (LDS | global, both executed by a wave whose lanes differ) was a tenth of a step's instructions
-    S.gates_fast = nullptr; S.num_gates_fast = 0;
+    // (gate_step<..., FAST = false>: the by-value DScene is not written here)
     const uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
     const uint32_t nslots = depth == 0 ? fixed_n : B.counters[C_QUEUE + depth];
     const uint32_t n = nslots * n2;
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_AOW_ATTR k_ao_walk(DScene S, Rend
         for (int rep = 0; rep < RT_WALK_REPS; ++rep) {
             const bool go = active && i < ng && sp < RT_DEFER_ROOTS;
             if (__builtin_amdgcn_ballot_w64(go) == 0ull) break;
-            if (go) i = gate_step<STATS>(S, o, dir, rg, i, h, st, sp, cnt);
+            if (go) i = gate_step<STATS, false, false>(S, o, dir, rg, i, h, st, sp, cnt);
         }
     }
     close_cursor(qc, B.bq_roots, (uint32_t)REF_NONE, B.bq_cap);
