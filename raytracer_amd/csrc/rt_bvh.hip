@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR(WAVES) k_bvh(DScene 
         if (sp_ >= RT_LDS_STACK) { x.x = spill[(size_t)(sp_ - RT_LDS_STACK) * spill_stride].x; x.y = spill[(size_t)(sp_ - RT_LDS_STACK) * spill_stride].y; }
         return x;
     };
-    uint32_t n = B.counters[counter];
+    uint32_t n = __builtin_amdgcn_readfirstlane(B.counters[counter]);   // wave-uniform values belong in scalar registers: as plain loads / shuffles the queue bookkeeping below ran on the vector unit
     if (n > (AO ? B.bq_cap : B.cq_cap)) n = AO ? B.bq_cap : B.cq_cap;
     // a wave takes at least 64 items, so waves beyond ceil(n/64) have nothing to fetch: they leave before touching
     // the queue counter (the launches of the deeper levels of a small frame hold a few hundred rays for 8192 waves)
@@ -105,6 +105,7 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR(WAVES) k_bvh(DScene 
     const uint32_t lane = threadIdx.x & 63u;
     f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
     RayCull4 rc = {};
+    SelFar sf = {0u, 0u, 0u};   // the exit planes' byte selectors, held (74 VGPRs leave room at 6 waves per SIMD): three xors fewer per node step
     Hit best = {};
     uint32_t sp = 0, cur = REF_NONE, dst = 0;
     // the parked leaves of the lane
@@ -150,7 +151,7 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR(WAVES) k_bvh(DScene 
                 if (chunk_end == 0) take = RT_BVH_CHUNK;   // first grab: position unknown
                 uint32_t b0 = 0;
                 if (lane == 0) b0 = atomicAdd(next, take);
-                b0 = __shfl(b0, 0);
+                b0 = __builtin_amdgcn_readfirstlane(b0);   // every lane of the wave is here (the conditions above are wave-uniform)
                 chunk_next = b0; chunk_end = b0 + take < n ? b0 + take : n;
                 if (b0 >= n) { exhausted = true; chunk_next = chunk_end = 0; }
             }
@@ -168,6 +169,7 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR(WAVES) k_bvh(DScene 
                     best.t = a.w; best.prim = H_MISS; best.rank = 0; best.u = 0; best.v = 0;
                     if (!AO) { const q4 c = B.bq_c[idx]; best.prim = f2u(c.x); best.rank = f2u(c.y); best.u = c.z; best.v = c.w; }
                     rc = make_cull4(S, o, d);
+                    sf = SelFar{f2u(rc.spx.y) ^ RT_PERM_FLIP, f2u(rc.spy.y) ^ RT_PERM_FLIP, f2u(rc.spz.y) ^ RT_PERM_FLIP};
                     sp = 0; PEND_CLEAR(); tri = 0;
                     if (root0 != REF_NONE) {
                         push(sp, root0, -INFINITY);
@@ -211,7 +213,7 @@ __global__ void __launch_bounds__(RT_BVH_BLOCK) RT_BVH_ATTR(WAVES) k_bvh(DScene 
                         uint32_t r4[4];
                         if (STATS) cnt.nodes++;
                         // one 64-byte fetch, four box tests, children sorted farthest first (missed ones last)
-                        const uint32_t nh = node_children_desc(S, rc, cur, best.t, t4, r4);
+                        const uint32_t nh = node_children_desc(S, rc, cur, best.t, t4, r4, sf);
                         if (sp + 4u <= RT_LDS_STACK) {   // all four pairs at fixed offsets, no predication: what lies beyond sp + nh is never read
                             uint2* top = s_stack + sp * RT_BVH_BLOCK + threadIdx.x;
                             top[0 * RT_BVH_BLOCK] = make_uint2(r4[0], f2u(t4[0]));

@@ -547,9 +547,11 @@ RT_FN float perm_q(uint32_t w, uint32_t sel)
 }
 
 // entry / exit distance of one axis: {near, far} = {2^23 + q_near, 2^23 + q_far} * s + {c.x, c.y}
-RT_FN void slab_axis(uint32_t w, rt_v2f sp, rt_v2f c, float& tn, float& tf)
+// sel_far = the exit plane's selector when the caller holds it in a register (k_bvh, which has registers to spare at its
+// occupancy), 0 = derive it from the entry selector here (one xor per axis and node)
+RT_FN void slab_axis(uint32_t w, rt_v2f sp, rt_v2f c, float& tn, float& tf, uint32_t sel_far_held = 0u)
 {
-    const uint32_t sel_near = f2u(sp.y), sel_far = sel_near ^ RT_PERM_FLIP;
+    const uint32_t sel_near = f2u(sp.y), sel_far = sel_far_held ? sel_far_held : sel_near ^ RT_PERM_FLIP;
 #if defined(__HIP_DEVICE_COMPILE__)
     const rt_v2f q = {perm_q(w, sel_near), perm_q(w, sel_far)};
     rt_v2f t;
@@ -562,12 +564,13 @@ RT_FN void slab_axis(uint32_t w, rt_v2f sp, rt_v2f c, float& tn, float& tf)
 #endif
 }
 
-RT_FN bool cull_box4(const RayCull4& rc, uint32_t wx, uint32_t wy, uint32_t wz, float tbest, float& tnear)
+struct SelFar { uint32_t x, y, z; };   // the three exit-plane selectors, or zeros (see slab_axis)
+RT_FN bool cull_box4(const RayCull4& rc, uint32_t wx, uint32_t wy, uint32_t wz, float tbest, float& tnear, SelFar sf = SelFar{0u, 0u, 0u})
 {
     float ax, bx, ay, by, az, bz;
-    slab_axis(wx, rc.spx, rc.cx, ax, bx);
-    slab_axis(wy, rc.spy, rc.cy, ay, by);
-    slab_axis(wz, rc.spz, rc.cz, az, bz);
+    slab_axis(wx, rc.spx, rc.cx, ax, bx, sf.x);
+    slab_axis(wy, rc.spy, rc.cy, ay, by, sf.y);
+    slab_axis(wz, rc.spz, rc.cz, az, bz, sf.z);
     const float n = fmaxf(fmaxf(ax, ay), az), f = fminf(fminf(bx, by), bz);
     tnear = n;
     return n <= f && n <= tbest;
@@ -587,13 +590,13 @@ RT_FN bool gate_maybe4(const RayCull4& rc, uint32_t wx, uint32_t wy, uint32_t wz
 }
 
 // the four child boxes of a 64-byte node (every slot holds a valid reference: see collapse_node)
-RT_FN void node_test4(const RayCull4& rc, q4 n0, q4 n1, q4 n2, q4 n3, float tbest, bool* h, float* t, uint32_t* r)
+RT_FN void node_test4(const RayCull4& rc, q4 n0, q4 n1, q4 n2, q4 n3, float tbest, bool* h, float* t, uint32_t* r, SelFar sf = SelFar{0u, 0u, 0u})
 {
     r[0] = f2u(n3.x); r[1] = f2u(n3.y); r[2] = f2u(n3.z); r[3] = f2u(n3.w);
-    h[0] = cull_box4(rc, f2u(n0.x), f2u(n0.y), f2u(n0.z), tbest, t[0]);
-    h[1] = cull_box4(rc, f2u(n0.w), f2u(n1.x), f2u(n1.y), tbest, t[1]);
-    h[2] = cull_box4(rc, f2u(n1.z), f2u(n1.w), f2u(n2.x), tbest, t[2]);
-    h[3] = cull_box4(rc, f2u(n2.y), f2u(n2.z), f2u(n2.w), tbest, t[3]);
+    h[0] = cull_box4(rc, f2u(n0.x), f2u(n0.y), f2u(n0.z), tbest, t[0], sf);
+    h[1] = cull_box4(rc, f2u(n0.w), f2u(n1.x), f2u(n1.y), tbest, t[1], sf);
+    h[2] = cull_box4(rc, f2u(n1.z), f2u(n1.w), f2u(n2.x), tbest, t[2], sf);
+    h[3] = cull_box4(rc, f2u(n2.y), f2u(n2.z), f2u(n2.w), tbest, t[3], sf);
 }
 
 // compare-exchange of (distance, reference) pairs: afterwards ta <= tb
@@ -628,12 +631,12 @@ RT_FN uint32_t node_children(const DScene& S, const RayCull4& rc, uint32_t node,
 // missed ones (distance -inf) last, so that a lane can store all four {reference, distance} pairs at consecutive
 // stack positions without predication and advance its stack pointer by the number of hits: the nearest hit child
 // ends on top, what lies beyond the new top is never read.
-RT_FN uint32_t node_children_desc(const DScene& S, const RayCull4& rc, uint32_t node, float tbest, float* t, uint32_t* r)
+RT_FN uint32_t node_children_desc(const DScene& S, const RayCull4& rc, uint32_t node, float tbest, float* t, uint32_t* r, SelFar sf = SelFar{0u, 0u, 0u})
 {
     const q4* np = S.nodes + (size_t)node * 4;
     const q4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
     bool h[4];
-    node_test4(rc, n0, n1, n2, n3, tbest, h, t, r);
+    node_test4(rc, n0, n1, n2, n3, tbest, h, t, r, sf);
     uint32_t nh = 0;
     for (int c = 0; c < 4; ++c) {
         nh += h[c] ? 1u : 0u;

@@ -117,7 +117,7 @@ __device__ inline uint32_t queue_slot(uint32_t* counter)
     uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
     uint32_t base = 0;
     if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, (int)leader);
+    base = __builtin_amdgcn_readlane(base, leader);   // wave-uniform: a scalar register, not a vector one
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 #else
@@ -209,7 +209,7 @@ RT_FN uint32_t chunk_append(uint32_t* counter, bool want, QCursor& qc, uint32_t*
         uint32_t b0 = 0;
         const uint32_t chunk = qc.chunk ? qc.chunk : CHUNK;
         if (lane == 0) b0 = atomicAdd(counter, chunk);
-        b0 = __shfl(b0, 0);
+        b0 = __shfl(b0, 0);   // (as a scalar broadcast, readfirstlane, the gate-walk kernels measured 1 % slower: the cursor then competes for their scalar registers)
         qc.next = b0; qc.end = b0 + chunk;
     }
     const uint32_t slot = qc.next + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
