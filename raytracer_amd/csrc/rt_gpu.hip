@@ -1171,11 +1171,12 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
     const uint64_t per_tile = (uint64_t)RT_TILE * RT_TILE * (uint64_t)A.spp;
     const uint32_t nl = S.num_lights ? S.num_lights : 1;
     const uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
-    // Paths per batch.  Default: as many as the 31-bit ray ids of the BVH queue items allow (P * n^2 < 2^31), at
-    // most 64 Mi, in equal batches (4K, 16 spp, 4x4 AO: 2 batches of 1020 tiles, ~104 GB of the 288 GB) — every
-    // launch of a persistent kernel ends in a drain tail, so fewer, larger batches are faster (8 -> 4: +1 %; round 3,
-    // 4 -> 2 with the ids widened from 29 to 31 bits).
-    uint64_t want = p->batch_paths ? p->batch_paths : (64u << 20);
+    // Paths per batch.  Default: as many as the 31-bit ray ids of the BVH queue items allow (P * n^2 < 2^31) and as fit
+    // 85 % of the free device memory, in equal batches — every launch of a persistent kernel ends in a drain tail and
+    // sizes its grid for the batch, so fewer, larger batches are faster (8 -> 4: +1 %; round 3: 4 -> 2 with the ids widened
+    // from 29 to 31 bits, and 2 -> 1 without the former 64 Mi cap: 4K, 16 spp, 4x4 AO is ONE batch of 2040 tiles, 133.7 M
+    // paths, ~208 GB of the 288 GB: 145.0 -> 141.5 ms).
+    uint64_t want = p->batch_paths ? p->batch_paths : 0x7FFFFFFFull;
     if (!p->batch_paths) {
         want = std::min<uint64_t>(want, ((1ull << 31) - 1) / (n2 ? n2 : 1));
         want = std::min<uint64_t>(want, 0xFFFFFFFFull / nl);
@@ -1227,6 +1228,13 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
             ctx->error = "rt_render: batch too large for 32-bit queue entries; lower batch_paths"; return RT_ERR_UNSUPPORTED; }
         const size_t need = carve_batch(B, nullptr, P, levels_alloc, nl, n2);
         if (need <= ctx->batch_bytes) break;
+        if (!p->batch_paths && tiles_per_batch > 1) {   // a default batch leaves 15 % of what is free to the caller
+            size_t mem_free = 0, mem_total = 0;
+            if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && need > (mem_free + ctx->batch_bytes) / 100 * 85) {
+                tiles_per_batch = (tiles_per_batch + 1) / 2;
+                continue;
+            }
+        }
         HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->done_recorded) HIPCHECK(ctx, hipEventSynchronize(ctx->ev_done));   // a render still running on a caller's stream
         if (ctx->batch_mem) HIPCHECK(ctx, hipFree(ctx->batch_mem));
