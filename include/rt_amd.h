@@ -144,7 +144,10 @@ typedef struct rt_params {
     uint32_t seed;                /* key of the counter-based generator (include/rt_rng.h)  */
     int32_t tile_rank, tile_world;/* multi-GPU: this call renders the 64x64 tiles t with
                                      t % tile_world == tile_rank (0,1 = everything)         */
-    uint32_t batch_paths;         /* paths in flight per wavefront batch, 0 = default       */
+    uint32_t batch_paths;         /* paths in flight per wavefront batch, 0 = default: as
+                                     many as the queues' 31-bit ray ids allow, at most 85 % of
+                                     the free device memory (a 4K 16-spp frame with 4x4 AO is
+                                     one batch of ~208 GB); set it to bound the memory taken  */
     uint32_t flags;               /* RT_FLAG_*                                              */
 } rt_params;
 

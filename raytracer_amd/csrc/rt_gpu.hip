@@ -32,7 +32,7 @@ using namespace rt;
 // 4096 / 8192 / 16384 / 32768 / 65536 blocks; k_shadow 11.6 / 11.2 / 11.0 at 2048 / 4096 / 8192 (256-thread blocks); k_prep 5.3 -> 4.8
 // and k_shade 4.7 -> 4.0 at 1536; k_trace best at 2048.
 #ifndef RT_GRID_TRACE
-#define RT_GRID_TRACE RT_MAX_GRID
+#define RT_GRID_TRACE 4096   // round 3, one batch per 4K frame: k_trace 2.22 -> 1.96 ms against 2048 blocks
 #endif
 #ifndef RT_GRID_PREP
 #define RT_GRID_PREP 1536
