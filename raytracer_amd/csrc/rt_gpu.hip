@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(RT_OVF_BLOCK) k_shadow_overflow(DScene S, Rend
 #define RT_AO_WAVES 6
 #endif
 #ifndef RT_WAVE_WALK_MIN
-#define RT_WAVE_WALK_MIN 12u   // gate nodes behind the lead planes from which k_ao<WAVE> is used (config 3 has 7, the reference's main() scene 30)
+#define RT_WAVE_WALK_MIN 4u   // gate nodes behind the lead planes from which k_ao<WAVE> is used: with the fused gate classification and 7 waves per SIMD it also wins on config 3 (7 nodes: k_ao 33.3 -> 32.5 ms; 12 until then); the reference's main() scene has 30
 #endif
 #ifndef RT_AO_WAVES_INSTEP
 #define RT_AO_WAVES_INSTEP 7   // k_ao<WAVE>: 71 VGPRs without scratch (the per-lane walk needs 32 bytes of scratch at 7 waves: 33.9 -> 36.3 ms); config 4 k_ao 24.2 -> 23.7 ms at half size

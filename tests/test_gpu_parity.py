@@ -321,8 +321,8 @@ def test_refilling_gate_walk_matches_the_oracle(gpu, port, debug):
 @pytest.mark.parametrize("debug", ["256", "512", "264"], ids=["in_step_everywhere", "lane_by_lane_everywhere", "in_step_with_capped_queue"])
 def test_in_step_gate_walk_matches_the_oracle(gpu, port, debug):
     """k_ao<WAVE> (round 3): the wave walks the gate array in step, node data through scalar registers — the production
-    path of the reference's own scenes (12 or more gate nodes behind the room planes, at most 64 in all).  RT_DEBUG bit
-    256 forces it on every scene (incl. config 3's 7 nodes and the tunnel whose rays cross 14 meshes: more roots than a
+    path of scenes with 4 or more gate nodes behind the room planes, at most 64 in all.  RT_DEBUG bit
+    256 forces it on every scene (incl. the smallest ones and the tunnel whose rays cross 14 meshes: more roots than a
     queue item carries, so lanes wait in mid-walk), bit 512 forces the lane-by-lane walk on the scenes that would take
     the in-step one, 264 = in step with the work queue capped at 3000 items (overflow kernels)."""
     import os
