@@ -202,6 +202,9 @@ __global__ void __launch_bounds__(RT_OVF_BLOCK) k_shadow_overflow(DScene S, Rend
 #ifndef RT_AO_WAVES_INSTEP
 #define RT_AO_WAVES_INSTEP 7   // k_ao<WAVE>: 71 VGPRs without scratch (the per-lane walk needs 32 bytes of scratch at 7 waves: 33.9 -> 36.3 ms); config 4 k_ao 24.2 -> 23.7 ms at half size
 #endif
+#ifndef RT_WAVE_WALK_LONG
+#define RT_WAVE_WALK_LONG 12u   // ... and from this many, at 8 waves per SIMD (55 VGPRs either way): the longer in-step walk has more scalar-load latency to cover (config 4, 30 nodes: k_ao 320.7 -> 312.6 ms at its stated size; config 3, 7 nodes: 30.5 -> 30.7)
+#endif
 #define RT_AO_ATTR(W) __attribute__((amdgpu_waves_per_eu(W, W)))
 // WAVE: the wave walks the gate array in step, node data through scalar registers (walk_gates_wave): the reference's own
 // scenes (configs 1, 2, 4), where the per-lane walk diverges over node kinds.  No LDS copy of the gates is needed then.
@@ -260,9 +263,10 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_AO_ATTR(WAVES) k_ao(DScene S, Ren
 #endif
 // Round 3: 7 waves per SIMD (72 VGPRs, 12 dwords of scratch) instead of 4 — on config 5 the kernel takes 51.2 ms at 4 waves
 // (122 VGPRs, round 2), 45.8 at 5, 42.8 at 6, 41.6 at 7 and 48.1 at 8 (64 VGPRs: 23 dwords of scratch).  What freed the
-// registers: the fp64 constants through scalar registers and no machine LICM (see k_ao above).
+// registers: the fp64 constants through scalar registers and no machine LICM (see k_ao above).  Without SLP vectorisation
+// (Makefile GPU_FLAGS: 38.6 -> 36.5 ms at 7 waves) the 8-wave build spills 3 dwords only: 35.7 ms.
 #ifndef RT_AOW_WAVES
-#define RT_AOW_WAVES 7
+#define RT_AOW_WAVES 8
 #endif
 #define RT_AOW_ATTR __attribute__((amdgpu_waves_per_eu(RT_AOW_WAVES, RT_AOW_WAVES)))
 template <bool STATS>
@@ -755,7 +759,10 @@ struct GpuBackend {
         }
         const uint32_t g = grid_for(n, d == 0 ? RT_GRID_AO : RT_MAX_GRID);   // one thread per hit (n*n rays each): many short blocks
         timed(RT_K_AO, [&] {
-            if (wave_walk) {
+            if (wave_walk && S.num_gates - S.num_lead_planes >= RT_WAVE_WALK_LONG) {
+                if (stats) hipLaunchKernelGGL((k_ao<true, true, 8>), dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
+                else hipLaunchKernelGGL((k_ao<false, true, 8>), dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
+            } else if (wave_walk) {
                 if (stats) hipLaunchKernelGGL((k_ao<true, true, RT_AO_WAVES_INSTEP>), dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
                 else hipLaunchKernelGGL((k_ao<false, true, RT_AO_WAVES_INSTEP>), dim3(g), dim3(RT_BLOCK), 0, stream, S, A, B, d, n);
             } else {

@@ -39,9 +39,10 @@ def test_hot_kernels_keep_their_occupancy_and_stay_out_of_scratch():
         ("_Z5k_bvhILi1ELb0ELi6E", 6, 0),    # k_bvh<AO>, the dominant kernel
         ("_Z5k_bvhILi0ELb0ELi6E", 6, 0),    # k_bvh<closest>
         ("_Z5k_bvhILi2ELb0ELi6E", 6, 0),    # k_bvh<shadow>
-        ("_Z4k_aoILb0ELb0ELi6E", 6, 0),     # k_ao, per-lane walk (config 3)
-        ("_Z4k_aoILb0ELb1ELi7E", 7, 0),     # k_ao<WAVE>, the walk in step (configs 1, 2, 4)
-        ("_Z9k_ao_walkILb0E", 7, 64),       # k_ao_walk (config 5): a few spilled dwords are the measured optimum
+        ("_Z4k_aoILb0ELb0ELi6E", 6, 0),     # k_ao, per-lane walk (fewer than 4 gate nodes behind the room planes)
+        ("_Z4k_aoILb0ELb1ELi7E", 7, 0),     # k_ao<WAVE>, the walk in step (config 3)
+        ("_Z4k_aoILb0ELb1ELi8E", 8, 0),     # ... over 12 gate nodes or more (configs 1, 2, 4)
+        ("_Z9k_ao_walkILb0E", 8, 16),       # k_ao_walk (config 5): 3 spilled dwords are the measured optimum
         ("_Z7k_traceILb0E", 6, 0),
         ("_Z14k_shadow_deferILb0E", 6, 0),
     ]
@@ -51,3 +52,6 @@ def test_hot_kernels_keep_their_occupancy_and_stay_out_of_scratch():
         assert k["ScratchSize"] <= scratch, (prefix, k)
     # six blocks of k_bvh per CU: 160 KB of LDS
     assert one("_Z5k_bvhILi1ELb0ELi6E")["LDS"] * 6 <= 160 * 1024
+    # ... and eight of the gate-walking kernels
+    assert one("_Z4k_aoILb0ELb1ELi8E")["LDS"] * 8 <= 160 * 1024
+    assert one("_Z9k_ao_walkILb0E")["LDS"] * 8 <= 160 * 1024
