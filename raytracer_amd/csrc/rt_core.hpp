@@ -1200,9 +1200,20 @@ __device__ inline double rt_k64()
     return c.d;
 }
 #define RT_K64(bits) rt_k64<bits>()
+// fma(a, b, K) with the constant as the instruction's scalar ADDEND: left to itself the compiler picks the two-address
+// v_fmac_f64 here and first copies the constant into a vector pair (two v_mov_b32 per Horner step of sincos_f64)
+template <uint64_t BITS>
+__device__ inline double rt_fma_k64(double a, double b)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(rt_k64<BITS>()));
+    return r;
+}
+#define RT_FMA_K64(a, b, bits) rt_fma_k64<bits>(a, b)
 #else
 inline double rt_k64_host(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
 #define RT_K64(bits) rt_k64_host(bits)
+#define RT_FMA_K64(a, b, bits) fma(a, b, rt_k64_host(bits))
 #endif
 
 // ---- ambient occlusion ray (Ambient::L, main.cpp:1361-1393; sampleHemisphere :4-19;
@@ -1230,17 +1241,17 @@ RT_FN void sincos_f64(double x, double& sn, double& cs)
     r = fma(-k, RT_K64(0x3DD0B4611A626331ULL /* 6.07710050650619224932e-11 */), r);
     const double z = r * r;
     double ps = fma(z, RT_K64(0x3DE5D93A5ACFD57CULL /* 1.58969099521155010221e-10 */), RT_K64(0xBE5AE5E68A2B9CEBULL /* -2.50507602534068634195e-08 */));
-    ps = fma(z, ps, RT_K64(0x3EC71DE357B1FE7DULL /* 2.75573137070700676789e-06 */));
-    ps = fma(z, ps, RT_K64(0xBF2A01A019C161D5ULL /* -1.98412698298579493134e-04 */));
-    ps = fma(z, ps, RT_K64(0x3F8111111110F8A6ULL /* 8.33333333332248946124e-03 */));
-    ps = fma(z, ps, RT_K64(0xBFC5555555555549ULL /* -1.66666666666666324348e-01 */));
+    ps = RT_FMA_K64(z, ps, 0x3EC71DE357B1FE7DULL /* 2.75573137070700676789e-06 */);
+    ps = RT_FMA_K64(z, ps, 0xBF2A01A019C161D5ULL /* -1.98412698298579493134e-04 */);
+    ps = RT_FMA_K64(z, ps, 0x3F8111111110F8A6ULL /* 8.33333333332248946124e-03 */);
+    ps = RT_FMA_K64(z, ps, 0xBFC5555555555549ULL /* -1.66666666666666324348e-01 */);
     const double s = fma(r * z, ps, r);
     double pc = fma(z, RT_K64(0xBDA8FAE9BE8838D4ULL /* -1.13596475577881948265e-11 */), RT_K64(0x3E21EE9EBDB4B1C4ULL /* 2.08757232129817482790e-09 */));
-    pc = fma(z, pc, RT_K64(0xBE927E4F809C52ADULL /* -2.75573143513906633035e-07 */));
-    pc = fma(z, pc, RT_K64(0x3EFA01A019CB1590ULL /* 2.48015872894767294178e-05 */));
-    pc = fma(z, pc, RT_K64(0xBF56C16C16C15177ULL /* -1.38888888888741095749e-03 */));
-    pc = fma(z, pc, RT_K64(0x3FA555555555554CULL /* 4.16666666666666019037e-02 */));
-    const double c = fma(z * z, pc, fma(z, RT_K64(0xBFE0000000000000ULL /* -0.5 */), RT_K64(0x3FF0000000000000ULL /* 1.0 */)));
+    pc = RT_FMA_K64(z, pc, 0xBE927E4F809C52ADULL /* -2.75573143513906633035e-07 */);
+    pc = RT_FMA_K64(z, pc, 0x3EFA01A019CB1590ULL /* 2.48015872894767294178e-05 */);
+    pc = RT_FMA_K64(z, pc, 0xBF56C16C16C15177ULL /* -1.38888888888741095749e-03 */);
+    pc = RT_FMA_K64(z, pc, 0x3FA555555555554CULL /* 4.16666666666666019037e-02 */);
+    const double c = fma(z * z, pc, fma(z, -0.5, 1.0));   // -0.5 and 1.0 are inline operands of v_fma_f64
     const int n = (int)k & 3;
     sn = (n & 1) ? c : s; cs = (n & 1) ? s : c;
     if (n & 2) sn = -sn;
@@ -1256,6 +1267,25 @@ RT_FN void ao_frame(f3 P, f3 N, f3& o, f3& u, f3& w)
     o = P + N * 0.01f;
 }
 
+// sqrtf(x) for x that is 0, negative, NaN or at least 2^-96 — never a tiny positive number: the correctly rounded root as the
+// compiler's own expansion computes it (v_sqrt_f32, then the one-ulp neighbours tried against x by fma), without that
+// expansion's rescaling of inputs below 2^-96, which is 5 of its 16 instructions.  Both square roots of ao_dir qualify:
+// 1 - sampleX^2 is 0 or a multiple of 2^-25, and the direction before normalisation has length ~1.
+RT_FN float sqrt_not_tiny(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const uint32_t sb = __builtin_bit_cast(uint32_t, s);
+    const float lo = __builtin_bit_cast(float, sb - 1u), hi = __builtin_bit_cast(float, sb + 1u);
+    const float elo = __builtin_fmaf(-lo, s, x), ehi = __builtin_fmaf(-hi, s, x);
+    float r = elo <= 0.0f ? lo : s;
+    r = ehi > 0.0f ? hi : r;
+    return __builtin_amdgcn_classf(x, 0x260 /* +-0, +inf */) ? x : r;
+#else
+    return sqrtf(x);
+#endif
+}
+
 // Direction of AO ray k (stratum x = k / n, y = k % n) in the frame (u, w)
 RT_FN f3 ao_dir(const rt_ambient& A, f3 u, f3 w, uint32_t rng_prefix, uint32_t ao_call, uint32_t k)
 {
@@ -1266,7 +1296,7 @@ RT_FN f3 ao_dir(const rt_ambient& A, f3 u, f3 w, uint32_t rng_prefix, uint32_t a
     int r0 = (int)rt_rand31_finish(rng_prefix, ctr), r1 = (int)rt_rand31_finish(rng_prefix, ctr + 1);
     float sampleX = (float)x * grid + (float)((div_rand_max(r0)) * (double)grid);
     float sampleY = (float)y * grid + (float)((div_rand_max(r1)) * (double)grid);
-    float r = sqrtf(1.0f - sampleX * sampleX);
+    float r = sqrt_not_tiny(1.0f - sampleX * sampleX);
     float phi = 2 * 3.14159265358979323846264338327950288f * sampleY;
     // glibc's cosf/sinf are (almost always) correctly rounded; get the same bits from fp64
     double sn, cs;
@@ -1274,7 +1304,7 @@ RT_FN f3 ao_dir(const rt_ambient& A, f3 u, f3 w, uint32_t rng_prefix, uint32_t a
     f3 h = F3((float)cs * r, sampleX, (float)sn * r);
     f3 v = cross(w, u);
     f3 rr = (u * h.x + w * h.y) + (v * h.z + F3(0.0f, 0.0f, 0.0f));
-    return normalize(rr);
+    return rr * (1.0f / sqrt_not_tiny(dot(rr, rr)));   // normalize()
 }
 
 // Transparency::refraction (main.cpp:1566-1592)
