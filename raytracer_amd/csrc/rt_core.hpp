@@ -1286,8 +1286,8 @@ RT_FN float sqrt_not_tiny(float x)
 #endif
 }
 
-// Direction of AO ray k (stratum x = k / n, y = k % n) in the frame (u, w)
-RT_FN f3 ao_dir(const rt_ambient& A, f3 u, f3 w, uint32_t rng_prefix, uint32_t ao_call, uint32_t k)
+// Direction of AO ray k (stratum x = k / n, y = k % n) in the frame (u, w); v = cross(w, u), the same for all rays of the hit
+RT_FN f3 ao_dir(const rt_ambient& A, f3 u, f3 w, f3 v, uint32_t rng_prefix, uint32_t ao_call, uint32_t k)
 {
     unsigned n = (unsigned)A.occlusion_samples;
     uint32_t x = k / n, y = k % n;
@@ -1302,9 +1302,12 @@ RT_FN f3 ao_dir(const rt_ambient& A, f3 u, f3 w, uint32_t rng_prefix, uint32_t a
     double sn, cs;
     sincos_f64((double)phi, sn, cs);
     f3 h = F3((float)cs * r, sampleX, (float)sn * r);
-    f3 v = cross(w, u);
     f3 rr = (u * h.x + w * h.y) + (v * h.z + F3(0.0f, 0.0f, 0.0f));
     return rr * (1.0f / sqrt_not_tiny(dot(rr, rr)));   // normalize()
+}
+RT_FN f3 ao_dir(const rt_ambient& A, f3 u, f3 w, uint32_t rng_prefix, uint32_t ao_call, uint32_t k)
+{
+    return ao_dir(A, u, w, cross(w, u), rng_prefix, ao_call, k);
 }
 
 // Transparency::refraction (main.cpp:1566-1592)

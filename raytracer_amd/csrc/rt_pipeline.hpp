@@ -536,7 +536,16 @@ RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int dep
 {
     const uint32_t n2 = (uint32_t)(S.ambient.occlusion_samples * S.ambient.occlusion_samples);
     // slot = position of the path in this depth's path list; paths without AO rays hold no path id
+    // The frame is read once per hit and held across the walks of its n*n rays (round 3: the gate-walk kernels have the
+    // registers for it since they are built without SLP vectorisation; until then it was re-read for every stratum).
+#ifndef RT_AO_REREAD
+    q4 ro = {0, 0, 0, 0}, ru = ro, rw = ro;
+    if (valid) { rw = B.ao_w[slot]; valid = f2u(rw.w) != 0xFFFFFFFFu; }
+    if (valid) { ro = B.ao_o[slot]; ru = B.ao_u[slot]; }
+    const f3 rv = cross(xyz(rw), xyz(ru));
+#else
     if (valid) valid = f2u(B.ao_w[slot].w) != 0xFFFFFFFFu;
+#endif
     for (uint32_t k = 0; k < n2; ++k) {   // wave-uniform
         f3 o = F3(0, 0, 0), dir = F3(0, 0, 1);
         Hit h; h.t = S.ambient.occlusion_dist; h.prim = H_MISS; h.u = 0; h.v = 0; h.rank = 0;
@@ -544,12 +553,13 @@ RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int dep
         const uint32_t dst = (uint32_t)ao_index(B, slot, k);
         RayGate rg = {};
         if (valid) {
-            // the frame is re-read for every stratum (48 bytes, served by the vector L1 after the first): keeping it in
-            // registers across the walk costs the kernel a wave of occupancy
+#ifdef RT_AO_REREAD
             const q4 ro = B.ao_o[slot], ru = B.ao_u[slot], rw = B.ao_w[slot];
+            const f3 rv = cross(xyz(rw), xyz(ru));
+#endif
             cnt.rays++;
             o = xyz(ro);
-            dir = ao_dir(S.ambient, xyz(ru), xyz(rw), f2u(ro.w), f2u(rw.w), k);
+            dir = ao_dir(S.ambient, xyz(ru), xyz(rw), rv, f2u(ro.w), f2u(rw.w), k);
             rg = make_gate(S.cull_pad, S.extent, o, dir);
             i = (S.debug & 2u) ? S.num_gates : lead_planes_hit(S, o, dir, rg, h);
         }
