@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_AOW_ATTR k_ao_walk(DScene S, Rend
         for (int rep = 0; rep < RT_WALK_REPS; ++rep) {
             const bool go = active && i < ng && sp < RT_DEFER_ROOTS;
             if (__builtin_amdgcn_ballot_w64(go) == 0ull) break;
-            if (go) i = gate_step<STATS, false, false>(S, o, dir, rg, i, h, st, sp, cnt);
+            if (go) i = gate_step<STATS, true, false>(S, o, dir, rg, i, h, st, sp, cnt);   // DIST: only the distance leaves the walk
         }
     }
     close_cursor(qc, B.bq_roots, (uint32_t)REF_NONE, B.bq_cap);

@@ -42,7 +42,7 @@ def test_hot_kernels_keep_their_occupancy_and_stay_out_of_scratch():
         ("_Z4k_aoILb0ELb0ELi6E", 6, 0),     # k_ao, per-lane walk (fewer than 4 gate nodes behind the room planes)
         ("_Z4k_aoILb0ELb1ELi7E", 7, 0),     # k_ao<WAVE>, the walk in step (config 3)
         ("_Z4k_aoILb0ELb1ELi8E", 8, 16),    # ... over 12 gate nodes or more (configs 1, 2, 4): 3 spilled dwords (the AO frame held across the strata) measure the same as none
-        ("_Z9k_ao_walkILb0E", 8, 16),       # k_ao_walk (config 5): 3 spilled dwords are the measured optimum
+        ("_Z9k_ao_walkILb0E", 8, 0),        # k_ao_walk (config 5)
         ("_Z7k_traceILb0E", 6, 0),
         ("_Z14k_shadow_deferILb0E", 6, 0),
     ]
