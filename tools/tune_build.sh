@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../raytracer_amd/csrc"
 mkdir -p ../../tune
 T=$(mktemp -d)
 F="--offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -I../../include -I. -w"
-B="${3--mllvm -amdgpu-sched-strategy=iterative-ilp}"
+B="${3--mllvm -amdgpu-sched-strategy=iterative-ilp -mllvm -slp-threshold=1}"
 G="${4--mllvm -amdgpu-sched-strategy=max-ilp -mllvm -disable-machine-licm -fno-slp-vectorize}"
 /opt/rocm/bin/hipcc $F $2 $B -c rt_bvh.hip -o $T/rt_bvh.o &
 /opt/rocm/bin/hipcc $F $2 $G -c rt_gpu.hip -o $T/rt_gpu.o &
