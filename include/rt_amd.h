@@ -296,6 +296,13 @@ enum { RT_BUILDER_HOST_SAH = 0, RT_BUILDER_GPU_LBVH = 1 };
 int rt_scene_set_builder(rt_scene* scene, int builder);
 int rt_scene_builder_used(rt_scene* scene, int* builder, double* build_seconds);
 
+/* Self-test of the hand-written device arithmetic behind Ambient::L's sample directions (main.cpp:1361-1393, :4-19): for n
+ * pseudo-random inputs it compares, bit for bit and on the device, (0) the exact square root without small-input rescaling
+ * against sqrtf, (1, 2) sin / cos with scalar-operand fma steps against the same polynomial written plainly, (3) the
+ * division-free r / RAND_MAX against the fp64 division; mismatches[k] counts the inputs that differ (all 0 when sound).
+ * [no reference counterpart: a check of this library's own arithmetic, for its GPU tests] */
+int rt_selftest_device_math(rt_ctx* ctx, uint64_t n, uint64_t seed, uint64_t mismatches[4]);
+
 /* Resolve step of saveToFile (main.cpp:1842-1850): uchar(pixel*255), truncating, on device. */
 int rt_quantize_rgb8(rt_ctx* ctx, const float* d_rgb, size_t num_pixels, uint8_t* d_rgb8, void* stream);
 

@@ -123,7 +123,7 @@ _EXPORTS = [
     "rt_scene_set_desc", "rt_scene_commit", "rt_scene_destroy",
     "rt_render", "rt_render_device", "rt_owned_tiles", "rt_unpack_tiles", "rt_quantize_rgb8",
     "rt_bmp24_bytes", "rt_encode_bmp24", "rt_scene_set_builder", "rt_scene_builder_used",
-    "rt_render_device_noalloc", "rt_render_multi",
+    "rt_render_device_noalloc", "rt_render_multi", "rt_selftest_device_math",
 ]
 RT_NOALLOC_SCRATCH_BYTES = 384 << 20
 
@@ -194,6 +194,7 @@ def load_library(path=None):
     lib.rt_owned_tiles.argtypes = [C.POINTER(rt_params), C.c_int, C.c_int, C.POINTER(C.c_uint32)]
     lib.rt_unpack_tiles.argtypes = [vp, vp, C.POINTER(rt_params), C.c_int, C.c_int, vp, vp]
     lib.rt_quantize_rgb8.argtypes = [vp, vp, C.c_size_t, vp, vp]
+    lib.rt_selftest_device_math.argtypes = [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.rt_scene_set_builder.argtypes = [vp, C.c_int]
     lib.rt_scene_builder_used.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     lib.rt_bmp24_bytes.argtypes = [C.c_int, C.c_int]

@@ -1264,7 +1264,8 @@ RT_FN void ao_frame(f3 P, f3 N, f3& o, f3& u, f3& w)
     o = P + N * 0.01f;
 }
 
-// sqrtf(x) for x that is 0, negative, NaN or at least 2^-96 — never a tiny positive number: the correctly rounded root as the
+// sqrtf(x) for x that is 0, NaN, at least 2^-96, or negative and normal — never a tiny positive number or a negative denormal
+// (v_sqrt_f32 flushes denormal inputs: -denormal would give -0 where sqrtf gives NaN): the correctly rounded root as the
 // compiler's own expansion computes it (v_sqrt_f32, then the one-ulp neighbours tried against x by fma), without that
 // expansion's rescaling of inputs below 2^-96, which is 5 of its 16 instructions.  Both square roots of ao_dir qualify:
 // 1 - sampleX^2 is 0 or a multiple of 2^-25, and the direction before normalisation has length ~1.

@@ -521,6 +521,59 @@ __global__ void __launch_bounds__(RT_BLOCK) k_unpack(const float* slab, float* f
 }
 
 // saveToFile's conversion (reference main.cpp:1847-1849): static_cast<unsigned char>(p * 255)
+// Self-test of the hand-written device arithmetic of the AO direction (rt_selftest_device_math): each against the plain
+// formulation the compiler expands itself.  out[0]: sqrt_not_tiny vs sqrtf; out[1] / out[2]: sin / cos of sincos_f64 vs the
+// same Horner steps written as fma() on literals; out[3]: div_rand_max vs the fp64 division.
+__device__ inline void sincos_f64_plain(double x, double& sn, double& cs)
+{
+    const double k = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632673412561417e+00, x);
+    r = fma(-k, 6.07710050650619224932e-11, r);
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double s = fma(r * z, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double c = fma(z * z, pc, fma(z, -0.5, 1.0));
+    const int n = (int)k & 3;
+    sn = (n & 1) ? c : s; cs = (n & 1) ? s : c;
+    if (n & 2) sn = -sn;
+    if ((n + 1) & 2) cs = -cs;
+}
+__global__ void __launch_bounds__(RT_BLOCK) k_selftest_math(unsigned long long n, unsigned long long seed, unsigned long long* out)
+{
+    unsigned bad[4] = {0, 0, 0, 0};
+    for (unsigned long long i = (unsigned long long)blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * RT_BLOCK) {
+        unsigned long long h = (i + seed) * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+        const uint32_t a = (uint32_t)h, b = (uint32_t)(h >> 32);
+        // (0) any bit pattern of the function's stated domain (not a positive number below 2^-96, not a negative denormal), and the AO argument 1 - s*s
+        float x = u2f(a);
+        if ((x > 0.0f && x < 0x1p-96f) || (x < 0.0f && x > -0x1p-126f)) x = 0.0f;
+        const float s01 = (float)(b >> 8) * 0x1p-24f, y = 1.0f - s01 * s01;
+        const float r0 = sqrt_not_tiny(x), e0 = sqrtf(x), r1 = sqrt_not_tiny(y), e1 = sqrtf(y);
+        if ((f2u(r0) != f2u(e0) && !(r0 != r0 && e0 != e0)) || f2u(r1) != f2u(e1)) bad[0]++;
+        // (1, 2) phi = 2*pi*sampleY as ao_dir forms it
+        const float phi = 2 * 3.14159265358979323846264338327950288f * ((float)(a >> 8) * 0x1p-24f);
+        double sn, cs, sn2, cs2;
+        sincos_f64((double)phi, sn, cs);
+        sincos_f64_plain((double)phi, sn2, cs2);
+        if (__double_as_longlong(sn) != __double_as_longlong(sn2)) bad[1]++;
+        if (__double_as_longlong(cs) != __double_as_longlong(cs2)) bad[2]++;
+        // (3)
+        const int r = (int)(b & 0x7FFFFFFFu);
+        if (__double_as_longlong(div_rand_max(r)) != __double_as_longlong((double)r / 2147483647.0)) bad[3]++;
+    }
+    for (int k = 0; k < 4; ++k) if (bad[k]) atomicAdd(&out[k], (unsigned long long)bad[k]);
+}
+
 __global__ void __launch_bounds__(RT_BLOCK) k_quantize(const float* rgb, uint8_t* out, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * RT_BLOCK)
@@ -1584,6 +1637,22 @@ int rt_quantize_rgb8(rt_ctx* ctx, const float* d_rgb, size_t num_pixels, uint8_t
     if (num_pixels) hipLaunchKernelGGL(k_quantize, dim3(grid_for(num_pixels * 3)), dim3(RT_BLOCK), 0, st, d_rgb, d_rgb8, num_pixels * 3);
     HIPCHECK(ctx, hipGetLastError());
     if (!stream) HIPCHECK(ctx, hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+int rt_selftest_device_math(rt_ctx* ctx, uint64_t n, uint64_t seed, uint64_t mismatches[4])
+{
+    if (!ctx || !mismatches) return RT_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHECK(ctx, hipSetDevice(ctx->device));
+    static_assert(ST_TOTAL >= 4, "the statistics array doubles as the self-test's counters");
+    HIPCHECK(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * 4, ctx->stream));
+    if (n) hipLaunchKernelGGL(k_selftest_math, dim3(grid_for(n > (1ull << 24) ? (1ull << 24) : n)), dim3(RT_BLOCK), 0, ctx->stream, (unsigned long long)n, (unsigned long long)seed, ctx->d_stats);
+    HIPCHECK(ctx, hipGetLastError());
+    unsigned long long h[4];
+    HIPCHECK(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 4; ++k) mismatches[k] = h[k];
     return RT_OK;
 }
 

@@ -124,6 +124,12 @@ class Renderer:
     def quantize_rgb8(self, d_rgb, num_pixels, d_rgb8, stream=None):
         self._check(self.lib.rt_quantize_rgb8(self.ctx, d_rgb, num_pixels, d_rgb8, stream), "rt_quantize_rgb8")
 
+    def selftest_device_math(self, n, seed=1):
+        """rt_selftest_device_math: mismatch counts [sqrt, sin, cos, r / RAND_MAX] over n pseudo-random inputs."""
+        out = (C.c_uint64 * 4)()
+        self._check(self.lib.rt_selftest_device_math(self.ctx, int(n), int(seed), out), "rt_selftest_device_math")
+        return [int(v) for v in out]
+
     def bmp24_bytes(self, width, height):
         return int(self.lib.rt_bmp24_bytes(int(width), int(height)))
 
