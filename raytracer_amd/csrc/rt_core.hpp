@@ -786,10 +786,11 @@ RT_FN uint32_t gate_step(const DScene& S, f3 o, f3 d, const RayGate& rg, uint32_
         const uint32_t kind = kindw & G_KIND_MASK;
         // The two box-gated kinds share ONE copy of the box test: lanes on inner gates and lanes on Mesh gates (about half
         // each in a walk over a BVHAccel of Meshes: config 5) then take it together instead of one kind after the other.
-        if (kind == G_GATED || kind >= G_MESH) {
+        static_assert(G_GATED == 1u && G_MESH == 5u && G_TRI == 4u, "the two box-gated kinds are the ones with (kind & 3) == 1");
+        if ((kindw & 3u) == 1u) {
             if (STATS) cnt.gates++;
             const bool pass = (kindw & G_SAME_BOX) || RT_GATE_ENTER(mn, mx, o, d, rg);
-            if (kind == G_GATED) return pass ? i + 1 : skip;
+            if (!(kindw & 4u)) return pass ? i + 1 : skip;   // G_GATED
             if (pass) st.p[(sp++) * st.stride] = f2u(tail().x);
             return i + 1;
         }

@@ -354,8 +354,9 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_AOW_ATTR k_ao_walk(DScene S, Rend
         // ---- RT_WALK_REPS gate nodes per lane ----
 #pragma nounroll
         for (int rep = 0; rep < RT_WALK_REPS; ++rep) {
-            const bool go = active && i < ng && sp < RT_DEFER_ROOTS;
-            if (__builtin_amdgcn_ballot_w64(go) == 0ull) break;
+            const bool go = i < ng && sp < RT_DEFER_ROOTS;   // (a lane without a ray holds i >= ng: it starts there and a ray ends there)
+            // (two ballots of plain compares: the ballot of their conjunction goes through a select and a second compare)
+            if ((__builtin_amdgcn_ballot_w64(i < ng) & __builtin_amdgcn_ballot_w64(sp < RT_DEFER_ROOTS)) == 0ull) break;
             if (go) i = gate_step<STATS, true, false>(S, o, dir, rg, i, h, st, sp, cnt);   // DIST: only the distance leaves the walk
         }
     }
