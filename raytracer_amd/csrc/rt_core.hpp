@@ -994,20 +994,41 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
             best.t = tmax; best.prim = H_MISS;
             cur_item = g.item;
         }
-        switch (g.kind & G_KIND_MASK) {
-        case G_GROUP:
-            i++;
-            break;
-        case G_GATED:
+        const uint32_t kind = g.kind & G_KIND_MASK;
+        if (kind == G_GATED || kind >= G_MESH) {
+            // ONE copy of the box test for inner gates and Mesh gates (as in gate_step): the lanes of a wave that sit on the two
+            // kinds take it together
             if (STATS) cnt.gates++;
-            i = ((g.kind & G_SAME_BOX) || RT_GATE_ENTER(g.mn, g.mx, o, d, rg)) ? i + 1 : g.skip;
-            break;
+            const bool pass = (g.kind & G_SAME_BOX) || RT_GATE_ENTER(g.mn, g.mx, o, d, rg);
+            if (kind == G_GATED) {
+                i = pass ? i + 1 : g.skip;
+            } else {   // G_MESH: defer its triangle BVH to the shared drain loop
+                bool next = true;
+                if (pass) {
+                    if (DEFER) {   // the caller queues the roots for k_bvh; one more than an item carries: the caller's overflow path
+                        if (sp < RT_DEFER_ROOTS) st.p[sp * st.stride] = g.a;
+                        if (++sp > RT_DEFER_ROOTS) { i = n; next = false; }
+                    } else {
+                        st.p[(sp++) * st.stride] = g.a;
+                        if (sp >= RT_PENDING_MAX) {
+                            const RayCull4 rc = make_cull4(S, o, d);
+                            if (MODE == 1 && S.item_opaque[g.item]) {
+                                if (bvh_drain<STATS, true>(S, o, d, rc, best, st, sp, cnt)) { shadowed = true; transparentOnly = false; i = n; next = false; }
+                            } else {
+                                bvh_drain<STATS, false>(S, o, d, rc, best, st, sp, cnt);
+                            }
+                        }
+                    }
+                }
+                if (next) i++;
+            }
+        } else {
+        switch (kind) {
         case G_PLANE: {
             float t;
             if (plane_t(F3(g.mn[0], g.mn[1], g.mn[2]), F3(g.mx[0], g.mx[1], g.mx[2]), o, d, t) && closer(t, g.rank, best)) {
                 best.t = t; best.prim = H_PLANE | g.a; best.rank = g.rank;
             }
-            i++;
             break;
         }
         case G_SPHERE: {
@@ -1015,7 +1036,6 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
             if (sphere_t(F3(g.mn[0], g.mn[1], g.mn[2]), g.mx[0], o, d, t) && closer(t, g.rank, best)) {
                 best.t = t; best.prim = H_SPHERE | g.a; best.rank = g.rank;
             }
-            i++;
             break;
         }
         case G_TRI: {
@@ -1026,31 +1046,12 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
             if (tri_t(xyz(a), xyz(b), xyz(e), o, d, t, u, v) && closer(t, g.rank, best)) {
                 best.t = t; best.prim = H_TRI | g.a; best.u = u; best.v = v; best.rank = g.rank;
             }
-            i++;
             break;
         }
-        default: { // G_MESH: gate, then defer its triangle BVH to the shared drain loop
-            if (STATS) cnt.gates++;
-            if ((g.kind & G_SAME_BOX) || RT_GATE_ENTER(g.mn, g.mx, o, d, rg)) {
-                if (DEFER) {   // the caller queues the roots for k_bvh; one more than an item carries: the caller's overflow path
-                    if (sp < RT_DEFER_ROOTS) st.p[sp * st.stride] = g.a;
-                    if (++sp > RT_DEFER_ROOTS) { i = n; break; }
-                    i++;
-                    break;
-                }
-                st.p[(sp++) * st.stride] = g.a;
-                if (sp >= RT_PENDING_MAX) {
-                    const RayCull4 rc = make_cull4(S, o, d);
-                    if (MODE == 1 && S.item_opaque[g.item]) {
-                        if (bvh_drain<STATS, true>(S, o, d, rc, best, st, sp, cnt)) { shadowed = true; transparentOnly = false; i = n; break; }
-                    } else {
-                        bvh_drain<STATS, false>(S, o, d, rc, best, st, sp, cnt);
-                    }
-                }
-            }
-            i++;
+        default:   // G_GROUP
             break;
         }
+        i++;
         }
         // end of the walk, or (shadow query) end of a world->scene entry: drain the deferred meshes
         if (!DEFER && sp > 0 && (i >= n || (MODE == 1 && load_gate(S, i).item != cur_item))) {
