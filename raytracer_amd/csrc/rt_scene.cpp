@@ -666,7 +666,7 @@ void HostScene::emit_shape(const rt_shape_ref& r, uint32_t item, uint32_t rank_b
     case RT_SHAPE_MULTIMESH: {
         // A MultiMesh of ONE Mesh whose box is bit-identical to its own: the reference tests the same box twice (MultiMesh::hit,
         // then Mesh::hit), with the same answer — one Mesh node with that box says the same with one gate node fewer on every
-        // walk (config 5: 2500 such shapes, 5.6 % of the AO walk's steps).
+        // walk (config 5: 2500 such shapes, 1.3 of the 101.5 gate tests per AO ray).
         if (multimeshes[r.index].num_meshes == 1 && !getenv("RT_KEEP_MM_GATE")) {
             const uint32_t mi = multimeshes[r.index].first_mesh;
             if (std::memcmp(mm_box_[r.index].mn, mesh_box_[mi].mn, 12) == 0 && std::memcmp(mm_box_[r.index].mx, mesh_box_[mi].mx, 12) == 0) { emit_mesh(mi, item, rank_base); break; }
