@@ -127,6 +127,10 @@ struct Stack { uint32_t* p; uint32_t stride; };  // entry i lives at p[i*stride]
 // Traversal stack: a 4-wide node pushes up to 3 children per level, the builders bound the depth at 13 four-wide
 // levels (25 two-wide ones), and up to RT_DEFER_ROOTS - 1 further mesh roots wait below: 3 * 13 + 7 = 46.
 #define RT_STACK_DEPTH 48
+// Entries an in-place traversal (bvh_drain) can hold at most over a two-wide tree with d2 inner levels: the roots that wait
+// (RT_PENDING_MAX) + 3 per four-wide level (a node is popped, up to four children are pushed), + 1 to spare.  The in-place
+// kernels size their LDS stacks by it (k_shadow: 24 / 32 / 48 entries per lane; 48 covers the builders' depth bound).
+#define RT_STACK_NEED(d2) (RT_PENDING_MAX + 3u * (((d2) + 1u) / 2u) + 1u)
 #define RT_DEFER_ROOTS 8   // mesh roots one queued BVH item can carry
 #define RT_PENDING_MAX 2   // deferred mesh roots before the inline drain loop is forced
 
@@ -648,7 +652,7 @@ RT_FN uint32_t node_children_desc(const DScene& S, const RayCull4& rc, uint32_t 
     return nh;
 }
 
-template <bool STATS, bool ANYHIT>
+template <bool STATS, bool ANYHIT, int DEPTH = RT_STACK_DEPTH>
 RT_FN bool bvh_drain(const DScene& S, f3 o, f3 d, const RayCull4& rc, Hit& best, Stack st, uint32_t& sp, Counters& cnt)
 {
     // Pops references until the stack is empty.  The stack holds the roots of every Mesh whose reference gate
@@ -667,7 +671,7 @@ RT_FN bool bvh_drain(const DScene& S, f3 o, f3 d, const RayCull4& rc, Hit& best,
             const uint32_t nh = node_children(S, rc, cur, best.t, t, r);
             // farthest first, so that the nearest child is popped next; depth is bounded by the builders
             for (int c = 3; c >= 0; --c)
-                if ((uint32_t)c < nh && sp < RT_STACK_DEPTH) st.p[(sp++) * st.stride] = r[c];
+                if ((uint32_t)c < nh && sp < (uint32_t)DEPTH) st.p[(sp++) * st.stride] = r[c];
             continue;
         }
         // cur is a leaf: up to 8 triangles stored contiguously
@@ -967,7 +971,7 @@ __device__ inline uint32_t walk_gates_wave(const DScene& S, f3 o, f3 d, const Ra
 //         roots are left on the stack and the count is returned (RT_DEFER_ROOTS + 1: more than one queue item
 //         carries, the walk was abandoned), so the caller can queue the ray for the any-hit variant of k_bvh.
 //         `shadow` is then the result as far as the primitives tested in place decide it.
-template <int MODE, bool STATS, bool DEFER = false>
+template <int MODE, bool STATS, bool DEFER = false, int DEPTH = RT_STACK_DEPTH>
 RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& shadow, Stack st, Counters& cnt)
 {
     best.t = tmax; best.prim = H_MISS; best.u = 0; best.v = 0; best.rank = 0;
@@ -977,7 +981,31 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
     uint32_t cur_item = 0;
     uint32_t i = 0, sp = 0;
     const uint32_t n = S.num_gates;
-    if (MODE == 0) i = lead_planes_hit(S, o, d, rg, best);   // the shadow query keeps per-entry state: it walks these nodes like any other
+    if (MODE == 0) i = lead_planes_hit(S, o, d, rg, best);
+    else if (DEFER) {   // (not in the kernel that traverses in place, k_shadow: there the compiler answers the indexed reads of the by-value scene with a copy of it in scratch memory, 520 bytes per lane)
+        // The shadow query keeps per-entry state, and each of the leading planes is a world->scene entry of its own: its closest
+        // hit is the plane's hit if t < tmax (closer() against {tmax, none}).  Same wave-uniform loop over the kernel arguments
+        // as lead_planes_hit, with the same cheap exclusion of axis planes whose approximate parameter is negative or beyond
+        // tmax by the margin (plane_axis_cannot_win) before the IEEE division — for a light inside the room that is all six.
+        bool stop = false;
+        for (uint32_t j = 0; j < S.num_lead_planes; ++j) {
+            const float* pl = S.lead_planes[j];
+            float t = 0.0f;
+            bool hit = false;
+            if (!stop) switch ((S.lead_axis >> (4u * j)) & 15u) {   // wave-uniform
+            case 0: hit = !plane_axis_cannot_win(pl[0], o.x, rg.ix, tmax) && plane_axis_t(pl[0], o.x, d.x, t); break;
+            case 1: hit = !plane_axis_cannot_win(pl[1], o.y, rg.iy, tmax) && plane_axis_t(pl[1], o.y, d.y, t); break;
+            case 2: hit = !plane_axis_cannot_win(pl[2], o.z, rg.iz, tmax) && plane_axis_t(pl[2], o.z, d.z, t); break;
+            default: hit = plane_t(F3(pl[0], pl[1], pl[2]), F3(pl[3], pl[4], pl[5]), o, d, t); break;
+            }
+            if (hit && t < tmax) {
+                shadowed = true;
+                transparentOnly = transparentOnly && (S.materials[f2u(S.planes[(size_t)f2u(pl[7]) * 2].w)].kind == RT_MAT_REFRACTION);
+                if (!transparentOnly) stop = true;   // an opaque entry in front of the light: decided
+            }
+        }
+        i = stop ? n : S.num_lead_planes;   // (the first node behind the planes belongs to a later entry: the loop below starts it afresh)
+    }
     while (i < n) {
         const GateNode g = load_gate(S, i);
         if (MODE == 1 && g.item != cur_item) {
@@ -1013,9 +1041,9 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
                         if (sp >= RT_PENDING_MAX) {
                             const RayCull4 rc = make_cull4(S, o, d);
                             if (MODE == 1 && S.item_opaque[g.item]) {
-                                if (bvh_drain<STATS, true>(S, o, d, rc, best, st, sp, cnt)) { shadowed = true; transparentOnly = false; i = n; next = false; }
+                                if (bvh_drain<STATS, true, DEPTH>(S, o, d, rc, best, st, sp, cnt)) { shadowed = true; transparentOnly = false; i = n; next = false; }
                             } else {
-                                bvh_drain<STATS, false>(S, o, d, rc, best, st, sp, cnt);
+                                bvh_drain<STATS, false, DEPTH>(S, o, d, rc, best, st, sp, cnt);
                             }
                         }
                     }
@@ -1057,9 +1085,9 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
         if (!DEFER && sp > 0 && (i >= n || (MODE == 1 && load_gate(S, i).item != cur_item))) {
             const RayCull4 rc = make_cull4(S, o, d);
             if (MODE == 1 && S.item_opaque[cur_item]) {
-                if (bvh_drain<STATS, true>(S, o, d, rc, best, st, sp, cnt)) { shadowed = true; transparentOnly = false; i = n; }
+                if (bvh_drain<STATS, true, DEPTH>(S, o, d, rc, best, st, sp, cnt)) { shadowed = true; transparentOnly = false; i = n; }
             } else {
-                bvh_drain<STATS, false>(S, o, d, rc, best, st, sp, cnt);
+                bvh_drain<STATS, false, DEPTH>(S, o, d, rc, best, st, sp, cnt);
             }
         }
     }

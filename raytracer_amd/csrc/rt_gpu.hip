@@ -128,17 +128,19 @@ __global__ void __launch_bounds__(RT_BLOCK) k_prep(DScene S, RenderArgs A, Batch
 #ifndef RT_SHADOW_BLOCK
 #define RT_SHADOW_BLOCK 128
 #endif
-template <bool STATS>
+template <bool STATS, int DEPTH>
 __global__ void __launch_bounds__(RT_SHADOW_BLOCK) k_shadow(DScene S, RenderArgs A, Batch B, int depth)
 {
-    __shared__ uint32_t s_stack[RT_STACK_DEPTH * RT_SHADOW_BLOCK];
+    // DEPTH entries per lane (24 / 32 / 48, chosen at launch from the depth of the scene's triangle BVHs, RT_STACK_NEED): at 48
+    // the 24 KB of a block leave 3 waves per SIMD; config 4 (trees of <= 14 levels) takes 51.6 ms at 48, 37.3 at 32, 35.6 at 24
+    __shared__ uint32_t s_stack[DEPTH * RT_SHADOW_BLOCK];
     __shared__ GateNode s_gates[RT_LDS_GATES];
     stage_gates(S, s_gates);
     const uint32_t n = B.counters[C_SH + depth] < B.sh_cap ? B.counters[C_SH + depth] : B.sh_cap;
     Stack st{s_stack + threadIdx.x, RT_SHADOW_BLOCK};
     Counters cnt{0, 0, 0, 0};
     for (uint32_t i = blockIdx.x * RT_SHADOW_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_SHADOW_BLOCK)
-        shadow_item<STATS>(S, A, B, depth, i, st, cnt);
+        shadow_item<STATS, DEPTH>(S, A, B, depth, i, st, cnt);
     flush_counters<STATS>(cnt, B.stats, 1);
 }
 
@@ -706,6 +708,7 @@ struct GpuBackend {
     hipError_t err = hipSuccess;
     bool wave_walk = false;   // k_ao<WAVE>: the gate walk in step (the reference's own scenes: a few dozen gate nodes of mixed kinds)
     bool walk_refill = false; size_t ovf_bits_bytes = 0;   // k_ao_walk instead of k_ao (scenes with many gate nodes)
+    uint32_t stack_need = RT_STACK_DEPTH;   // entries an in-place traversal of this scene's triangle BVHs can need (RT_STACK_NEED): sizes k_shadow's LDS stack
 
     size_t ev()
     {
@@ -786,8 +789,16 @@ struct GpuBackend {
             return;
         }
         timed(RT_K_SHADOW, [&] {
-            if (stats) hipLaunchKernelGGL(k_shadow<true>, dim3(g), dim3(RT_SHADOW_BLOCK), 0, stream, S, A, B, d);
-            else hipLaunchKernelGGL(k_shadow<false>, dim3(g), dim3(RT_SHADOW_BLOCK), 0, stream, S, A, B, d);
+            if (stack_need <= 24u) {
+                if (stats) hipLaunchKernelGGL((k_shadow<true, 24>), dim3(g), dim3(RT_SHADOW_BLOCK), 0, stream, S, A, B, d);
+                else hipLaunchKernelGGL((k_shadow<false, 24>), dim3(g), dim3(RT_SHADOW_BLOCK), 0, stream, S, A, B, d);
+            } else if (stack_need <= 32u) {
+                if (stats) hipLaunchKernelGGL((k_shadow<true, 32>), dim3(g), dim3(RT_SHADOW_BLOCK), 0, stream, S, A, B, d);
+                else hipLaunchKernelGGL((k_shadow<false, 32>), dim3(g), dim3(RT_SHADOW_BLOCK), 0, stream, S, A, B, d);
+            } else {
+                if (stats) hipLaunchKernelGGL((k_shadow<true, RT_STACK_DEPTH>), dim3(g), dim3(RT_SHADOW_BLOCK), 0, stream, S, A, B, d);
+                else hipLaunchKernelGGL((k_shadow<false, RT_STACK_DEPTH>), dim3(g), dim3(RT_SHADOW_BLOCK), 0, stream, S, A, B, d);
+            }
         });
     }
     void ao(const RenderArgs& A, int d, uint32_t n)
@@ -1319,6 +1330,7 @@ static int render_locked(rt_scene* s, const rt_camera* cam, const rt_params* p, 
     // experiment switches: RT_DEBUG bit 256 forces the in-step walk on, bit 512 off
     be.wave_walk = !be.walk_refill && (((S.num_gates <= RT_LDS_GATES && S.num_gates - S.num_lead_planes >= RT_WAVE_WALK_MIN) && !(S.debug & 512u)) || (S.debug & 256u));
     be.ovf_bits_bytes = 4ull * (B.ovf_cap / 32u + 1u);
+    be.stack_need = (S.debug & 1024u) ? (uint32_t)RT_STACK_DEPTH : RT_STACK_NEED(s->host.bvh_max_depth);   // RT_DEBUG bit 1024: the full-depth stack whatever the scene
     if ((S.debug & 4u) || (uint64_t)P * nl >= (1ull << 31)) be.S.shadow_defer = 0;   // experiment switch / the queue item's 31-bit destination
     if (!capturing) {   // the batch buffers, counters and statistics are the context's: wait for their previous user (any stream)
         const int rc = order_after_previous_work(ctx, stream);   // (a capturing stream may not wait on an event recorded outside the capture)

@@ -434,7 +434,7 @@ RT_FN void prep_item(const DScene& S, const RenderArgs& A, const Batch& B, int d
     }
 }
 
-template <bool STATS>
+template <bool STATS, int DEPTH = RT_STACK_DEPTH>
 RT_FN void shadow_item(const DScene& S, const RenderArgs& A, const Batch& B, int depth, uint32_t idx, Stack st, Counters& cnt)
 {
     uint32_t e = B.sh_queue[idx];
@@ -447,7 +447,7 @@ RT_FN void shadow_item(const DScene& S, const RenderArgs& A, const Batch& B, int
     f3 dir = normalize(P - src);
     float dist = length(P - src) - 0.01f;
     Hit h; float sh = 1.0f;
-    trace<1, STATS>(S, src, dir, dist, h, sh, st, cnt);
+    trace<1, STATS, false, DEPTH>(S, src, dir, dist, h, sh, st, cnt);
     B.sh_res[e] = sh;
 }
 

@@ -337,6 +337,28 @@ def test_in_step_gate_walk_matches_the_oracle(gpu, port, debug):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("debug", ["4", "1028"], ids=["stack_sized_by_the_scene", "full_depth_stack"])
+def test_in_place_shadow_kernel_matches_the_oracle(gpu, port, debug):
+    """k_shadow, the shadow kernel that traverses in place (the production path of scenes whose Meshes share a world->scene
+    entry with a transparent material: config 4; forced everywhere by RT_DEBUG bit 4), with its LDS stack sized by the depth
+    of the scene's triangle BVHs (24 / 32 / 48 entries per lane, RT_STACK_NEED) and, bit 1024, at the full 48 whatever
+    the scene.  Both builders: the device-built radix trees are the deeper ones."""
+    import os
+    os.environ["RT_DEBUG"] = debug
+    try:
+        for name, world, params in [c for c in CASES if c[0] in ("default_d2_ao", "config3_textured_mesh", "config4_depth8")]:
+            test_matches_oracle(gpu, port, name, world, params)
+            test_matches_reference_fixture(gpu, name, world, params, capi.RT_BUILDER_GPU_LBVH)
+        w = util.mesh_tunnel_scene(96, 72)
+        test_matches_oracle(gpu, port, "mesh_tunnel", w, w.params(seed=5))
+        for seed in (40089, 40403, 40497):
+            w, params = util.random_scene(seed)
+            test_matches_oracle(gpu, port, f"random_{seed}", w, params)
+    finally:
+        del os.environ["RT_DEBUG"]
+
+
+@pytest.mark.gpu
 def test_more_meshes_on_a_ray_than_deferred_roots(gpu, port):
     """Rays that pass the gates of 14 meshes: more than the 8 roots a queue item carries, so the walk
     drains inline in mid-walk and queues the rest."""
