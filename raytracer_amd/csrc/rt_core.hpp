@@ -982,25 +982,40 @@ RT_FN uint32_t trace(const DScene& S, f3 o, f3 d, float tmax, Hit& best, float& 
     uint32_t i = 0, sp = 0;
     const uint32_t n = S.num_gates;
     if (MODE == 0) i = lead_planes_hit(S, o, d, rg, best);
-    else if (DEFER) {   // (not in the kernel that traverses in place, k_shadow: there the compiler answers the indexed reads of the by-value scene with a copy of it in scratch memory, 520 bytes per lane)
+    else {
         // The shadow query keeps per-entry state, and each of the leading planes is a world->scene entry of its own: its closest
-        // hit is the plane's hit if t < tmax (closer() against {tmax, none}).  Same wave-uniform loop over the kernel arguments
-        // as lead_planes_hit, with the same cheap exclusion of axis planes whose approximate parameter is negative or beyond
-        // tmax by the margin (plane_axis_cannot_win) before the IEEE division — for a light inside the room that is all six.
+        // hit is the plane's hit if t < tmax (closer() against {tmax, none}).  Same wave-uniform loop as lead_planes_hit, with the
+        // same cheap exclusion of axis planes whose approximate parameter is negative or beyond tmax by the margin
+        // (plane_axis_cannot_win) before the IEEE division — for a light inside the room that is all six.  The deferring kernel
+        // reads the planes from the kernel arguments; k_shadow, which traverses in place, reads the same numbers from the gate
+        // array through scalar loads (indexed reads of the by-value scene made the compiler keep a copy of it in scratch memory
+        // there, 520 bytes per lane).
         bool stop = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef float rt_v4f __attribute__((ext_vector_type(4)));
+        const RT_CONST_AS rt_v4f* G = (const RT_CONST_AS rt_v4f*)(uintptr_t)S.gates;
+#endif
         for (uint32_t j = 0; j < S.num_lead_planes; ++j) {
-            const float* pl = S.lead_planes[j];
+            float px, py, pz, nx, ny, nz;
+            uint32_t plane;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (!DEFER) {
+                const rt_v4f g0 = G[3u * j], g1 = G[3u * j + 1u];
+                px = g0.x; py = g0.y; pz = g0.z; nx = g1.x; ny = g1.y; nz = g1.z; plane = f2u(G[3u * j + 2u].x);
+            } else
+#endif
+            { const float* pl = S.lead_planes[j]; px = pl[0]; py = pl[1]; pz = pl[2]; nx = pl[3]; ny = pl[4]; nz = pl[5]; plane = f2u(pl[7]); }
             float t = 0.0f;
             bool hit = false;
             if (!stop) switch ((S.lead_axis >> (4u * j)) & 15u) {   // wave-uniform
-            case 0: hit = !plane_axis_cannot_win(pl[0], o.x, rg.ix, tmax) && plane_axis_t(pl[0], o.x, d.x, t); break;
-            case 1: hit = !plane_axis_cannot_win(pl[1], o.y, rg.iy, tmax) && plane_axis_t(pl[1], o.y, d.y, t); break;
-            case 2: hit = !plane_axis_cannot_win(pl[2], o.z, rg.iz, tmax) && plane_axis_t(pl[2], o.z, d.z, t); break;
-            default: hit = plane_t(F3(pl[0], pl[1], pl[2]), F3(pl[3], pl[4], pl[5]), o, d, t); break;
+            case 0: hit = !plane_axis_cannot_win(px, o.x, rg.ix, tmax) && plane_axis_t(px, o.x, d.x, t); break;
+            case 1: hit = !plane_axis_cannot_win(py, o.y, rg.iy, tmax) && plane_axis_t(py, o.y, d.y, t); break;
+            case 2: hit = !plane_axis_cannot_win(pz, o.z, rg.iz, tmax) && plane_axis_t(pz, o.z, d.z, t); break;
+            default: hit = plane_t(F3(px, py, pz), F3(nx, ny, nz), o, d, t); break;
             }
             if (hit && t < tmax) {
                 shadowed = true;
-                transparentOnly = transparentOnly && (S.materials[f2u(S.planes[(size_t)f2u(pl[7]) * 2].w)].kind == RT_MAT_REFRACTION);
+                transparentOnly = transparentOnly && (S.materials[f2u(S.planes[(size_t)plane * 2].w)].kind == RT_MAT_REFRACTION);
                 if (!transparentOnly) stop = true;   // an opaque entry in front of the light: decided
             }
         }
