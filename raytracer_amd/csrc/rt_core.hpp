@@ -60,7 +60,7 @@ enum : uint32_t { G_GROUP = 0, G_GATED = 1, G_PLANE = 2, G_SPHERE = 3, G_TRI = 4
 // PLANE: mn = point, mx = normal; SPHERE: mn = centre, mx = {radius^2, radius, 0}.
 struct alignas(16) GateNode {
     float mn[3]; uint32_t kind;
-    float mx[3]; uint32_t skip;  // next node when this subtree is not entered
+    float mx[3]; uint32_t skip;  // G_GATED: next node when this subtree is not entered; G_MESH: the Mesh's root again (`a`); other kinds: the next node
     uint32_t a;                  // PLANE/SPHERE: index; TRI: triangle slot; MESH: root of its triangle BVH
     uint32_t rank;               // reference visiting order of the (first) primitive below
     uint32_t prim;               // MESH: global triangle index of its triangle 0
@@ -795,7 +795,7 @@ RT_FN uint32_t gate_step(const DScene& S, f3 o, f3 d, const RayGate& rg, uint32_
             if (STATS) cnt.gates++;
             const bool pass = (kindw & G_SAME_BOX) || RT_GATE_ENTER(mn, mx, o, d, rg);
             if (!(kindw & 4u)) return pass ? i + 1 : skip;   // G_GATED
-            if (pass) st.p[(sp++) * st.stride] = f2u(tail().x);
+            if (pass) st.p[(sp++) * st.stride] = skip;   // a Mesh node's `skip` word is its root: no second fetch (the node's last 16 bytes) in the step that queues it
             return i + 1;
         }
         switch (kind) {

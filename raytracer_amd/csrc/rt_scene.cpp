@@ -614,7 +614,7 @@ void HostScene::emit_mesh(uint32_t mesh, uint32_t item, uint32_t rank_base)
     GateNode g{};
     std::memcpy(g.mn, mesh_box_[mesh].mn, 12); std::memcpy(g.mx, mesh_box_[mesh].mx, 12);
     g.kind = G_MESH; g.a = mesh_bvh(mesh, rank_base); g.rank = rank_base; g.prim = meshes[mesh].first_triangle; g.item = item;
-    g.skip = (uint32_t)gates.size() + 1;
+    g.skip = g.a;   // a Mesh node is a leaf (its successor is the next node): the field carries the root a second time, inside the 32 bytes the per-lane walk fetches first (gate_step)
     gates.push_back(g);
 }
 
