@@ -946,7 +946,7 @@ __device__ inline uint32_t walk_gates_wave(const DScene& S, f3 o, f3 d, const Ra
             break;
         }
         default: {   // G_MESH
-            const uint32_t root = f2u(G[3u * j + 2u].x);
+            const uint32_t root = skip;   // a Mesh node's `skip` word is its root (no third scalar load)
             if (mine) {
                 if (STATS) cnt.gates++;
                 if ((kindw & G_SAME_BOX) || RT_GATE_ENTER(mn, mx, o, d, rg))

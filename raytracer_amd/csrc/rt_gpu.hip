@@ -332,9 +332,8 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_AOW_ATTR k_ao_walk(DScene S, Rend
                 item = mine;
                 uint32_t slot_ao, k;
                 ao_coords(S, nslots, item & ~255u, item & 255u, slot_ao, k);
-                const q4 rw = B.ao_w[slot_ao];
+                const q4 rw = B.ao_w[slot_ao], ro = B.ao_o[slot_ao], ru = B.ao_u[slot_ao];   // one round trip (the records of a path without AO rays are in range, stale, and not used)
                 if (f2u(rw.w) != 0xFFFFFFFFu) {   // else: a path without AO rays
-                    const q4 ro = B.ao_o[slot_ao], ru = B.ao_u[slot_ao];
                     cnt.rays++;
                     o = xyz(ro);
                     dir = ao_dir(S.ambient, xyz(ru), xyz(rw), f2u(ro.w), f2u(rw.w), k);
@@ -439,9 +438,8 @@ __global__ void __launch_bounds__(RT_WALKQ_BLOCK) k_ao_walk_lds(DScene S, Render
                 item = mine;
                 uint32_t slot_ao, k;
                 ao_coords(S, nslots, item & ~255u, item & 255u, slot_ao, k);
-                const q4 rw = B.ao_w[slot_ao];
+                const q4 rw = B.ao_w[slot_ao], ro = B.ao_o[slot_ao], ru = B.ao_u[slot_ao];   // one round trip (the records of a path without AO rays are in range, stale, and not used)
                 if (f2u(rw.w) != 0xFFFFFFFFu) {   // else: a path without AO rays
-                    const q4 ro = B.ao_o[slot_ao], ru = B.ao_u[slot_ao];
                     cnt.rays++;
                     o = xyz(ro);
                     dir = ao_dir(S.ambient, xyz(ru), xyz(rw), f2u(ro.w), f2u(rw.w), k);
