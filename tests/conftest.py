@@ -43,8 +43,7 @@ def emul():
     """tests/emul/libemul.so — host build of the device functions (CPU tests only)."""
     import util
     path = os.path.join(ROOT, "tests", "emul", "libemul.so")
-    if not os.path.exists(path):
-        _make("tests/emul", "libemul.so")
+    _make("tests/emul", "libemul.so")   # always: make compares time stamps, and a stale host build of the device headers would test old code
     return util.Emul(path)
 
 
