@@ -722,6 +722,8 @@ RT_FN bool plane_axis_cannot_win(float pa, float oa, float inv_da, float tbest)
     return (ta < -1e-30f) || (tbest > 1e-30f && ta > tbest * 1.000004f + 1e-30f);
 }
 
+// DIST (the occlusion walks): only the distance of the closest plane is kept (see gate_step).
+template <bool DIST = false>
 RT_FN uint32_t lead_planes_hit(const DScene& S, f3 o, f3 d, const RayGate& rg, Hit& best)
 {
     for (uint32_t j = 0; j < S.num_lead_planes; ++j) {
@@ -734,7 +736,8 @@ RT_FN uint32_t lead_planes_hit(const DScene& S, f3 o, f3 d, const RayGate& rg, H
         case 2: hit = !plane_axis_cannot_win(pl[2], o.z, rg.iz, best.t) && plane_axis_t(pl[2], o.z, d.z, t); break;
         default: hit = plane_t(F3(pl[0], pl[1], pl[2]), F3(pl[3], pl[4], pl[5]), o, d, t); break;
         }
-        if (hit && closer(t, f2u(pl[6]), best)) {
+        if (DIST) { if (hit && t < best.t) best.t = t; }
+        else if (hit && closer(t, f2u(pl[6]), best)) {
             best.t = t; best.prim = H_PLANE | f2u(pl[7]); best.rank = f2u(pl[6]);
         }
     }

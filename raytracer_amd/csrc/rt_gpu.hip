@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(RT_BLOCK) RT_AOW_ATTR k_ao_walk(DScene S, Rend
                     slot_of = slot_ao;
                     rg = make_gate(S.cull_pad, S.extent, o, dir);
                     h.t = S.ambient.occlusion_dist; h.prim = H_MISS; h.rank = 0;
-                    i = (S.debug & 2u) ? ng : lead_planes_hit(S, o, dir, rg, h);
+                    i = (S.debug & 2u) ? ng : lead_planes_hit<true>(S, o, dir, rg, h);
                     sp = 0;
                     active = true;
                 }
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(RT_WALKQ_BLOCK) k_ao_walk_lds(DScene S, Render
                     rg = make_gate(S.cull_pad, S.extent, o, dir);
                     gc = make_cull4_from(make_cull_grid(S.cull_pad, S.extent, S.gq_base, S.gq_scale, o, dir));
                     h.t = S.ambient.occlusion_dist; h.prim = H_MISS; h.rank = 0;
-                    i = (S.debug & 2u) ? ng : lead_planes_hit(S, o, dir, rg, h);
+                    i = (S.debug & 2u) ? ng : lead_planes_hit<true>(S, o, dir, rg, h);
                     sp = 0;
                     active = true;
                 }

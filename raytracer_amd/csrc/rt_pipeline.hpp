@@ -561,7 +561,7 @@ RT_FN void ao_item(const DScene& S, const RenderArgs& A, const Batch& B, int dep
             o = xyz(ro);
             dir = ao_dir(S.ambient, xyz(ru), xyz(rw), rv, f2u(ro.w), f2u(rw.w), k);
             rg = make_gate(S.cull_pad, S.extent, o, dir);
-            i = (S.debug & 2u) ? S.num_gates : lead_planes_hit(S, o, dir, rg, h);
+            i = (S.debug & 2u) ? S.num_gates : lead_planes_hit<true>(S, o, dir, rg, h);   // DIST: only h.t leaves this function
         }
         for (;;) {
 #if defined(__HIP_DEVICE_COMPILE__)
