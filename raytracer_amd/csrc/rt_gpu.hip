@@ -35,7 +35,7 @@ using namespace rt;
 #define RT_GRID_TRACE 4096   // round 3, one batch per 4K frame: k_trace 2.22 -> 1.96 ms against 2048 blocks
 #endif
 #ifndef RT_GRID_PREP
-#define RT_GRID_PREP 1536
+#define RT_GRID_PREP 1024   // re-swept at the end of round 3 on the one-batch frame (512 ... 8192): k_prep 4.47 -> 4.40 ms
 #endif
 #ifndef RT_GRID_SHADOW
 #define RT_GRID_SHADOW 16384   // blocks of RT_SHADOW_BLOCK threads
@@ -44,7 +44,7 @@ using namespace rt;
 #define RT_GRID_AO 32768
 #endif
 #ifndef RT_GRID_SHADE
-#define RT_GRID_SHADE 1536
+#define RT_GRID_SHADE 1792   // 7 blocks per CU = the kernel's 7 waves per SIMD, one resident round: k_shade 4.80 -> 4.58 ms (2048: 6.2)
 #endif
 constexpr uint32_t rt_max_u32(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
